@@ -1,0 +1,84 @@
+"""ctypes binding of ``libmi355yolo.so`` (C-ABI declared in ``include/mi355yolo.h``).
+
+There is deliberately NO fallback: if the shared library is missing or a symbol cannot be resolved the
+import of this module raises, and ``m355_create`` fails on a machine without a gfx950 device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmi355yolo.so")
+
+
+class M355Error(RuntimeError):
+    """Raised when a libmi355yolo call returns a negative status."""
+
+
+class ModelDesc(C.Structure):
+    _fields_ = [("scale", C.c_int), ("nc", C.c_int), ("in_h", C.c_int), ("in_w", C.c_int),
+                ("max_batch", C.c_int)]
+
+
+class ConvInfo(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("cin", C.c_int), ("cout", C.c_int), ("k", C.c_int),
+                ("stride", C.c_int), ("has_bn", C.c_int), ("transposed", C.c_int), ("act", C.c_int)]
+
+
+# symbol -> (restype, argtypes); every entry of include/mi355yolo.h
+_P = C.c_void_p
+_F = C.POINTER(C.c_float)
+SIGNATURES = {
+    "m355_version": (C.c_char_p, []),
+    "m355_last_error": (C.c_char_p, [_P]),
+    "m355_create": (C.c_int, [C.POINTER(ModelDesc), C.POINTER(_P)]),
+    "m355_destroy": (None, [_P]),
+    "m355_num_convs": (C.c_int, [_P]),
+    "m355_get_conv_info": (C.c_int, [_P, C.c_int, C.POINTER(ConvInfo)]),
+    "m355_num_anchors": (C.c_int, [_P]),
+    "m355_pred_width": (C.c_int, [_P]),
+    "m355_proto_hw": (C.c_int, [_P, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "m355_workspace_bytes": (C.c_size_t, [_P]),
+    "m355_flops_per_image": (C.c_double, [_P]),
+    "m355_set_conv_weights": (C.c_int, [_P, C.c_int, _P, _P]),
+    "m355_forward": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "m355_get_raw_head": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
+    "m355_copy_raw_head": (C.c_int, [_P, C.c_int, _P, _P]),
+    "m355_postprocess": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P, _P]),
+    "m355_conv2d_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
+                                  C.c_int, _P, _P, C.c_int, C.c_int, _P]),
+    "m355_convt2x2_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    "m355_stem_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
+    "m355_sppf_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "m355_upsample2x": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "m355_head_decode": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "m355_nms": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
+    "m355_proto_masks": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int, engine=None) -> None:
+    if rc < 0:
+        msg = lib.m355_last_error(engine)
+        raise M355Error(f"libmi355yolo error {rc}: {msg.decode() if msg else '?'}")
+
+
+def version() -> str:
+    return lib.m355_version().decode()

@@ -1,0 +1,69 @@
+// Shared declarations for libmi355yolo.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace m355 {
+
+typedef _Float16 half_t;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;  // K elements per main-loop step of the implicit GEMM (one 128-byte LDS row)
+
+// Arguments of the implicit-GEMM convolution kernel (all strides in ELEMENTS of the tensor's dtype).
+struct ConvArgs {
+  const half_t* x;     // input, NHWC fp16, already offset to the first input channel of the slice
+  long x_bstride;      // elements between images
+  int ldx;             // elements between pixels (total channels of the underlying buffer)
+  int Hi, Wi, Cin;
+  const half_t* w;     // packed weights [Cout_pad][Kpad], K = (kh*KS+kw)*Cin + cin
+  int Kpad;
+  const float* bias;   // [Cout_pad]
+  void* y;             // output, fp16 (or fp32 if out_f32), offset to first output channel of the slice
+  long y_bstride;
+  int ldy;
+  int Ho, Wo;          // output spatial size (for convT: equals Hi, Wi -- the GEMM's pixel grid)
+  int Cout;            // logical output channels (for convT: 4*Co virtual channels)
+  const half_t* res;   // optional residual (same pixel grid as y), offset to slice
+  long r_bstride;
+  int ldr;
+  int ksize, stride, pad;
+  int M;               // B*Ho*Wo
+  int act;             // 1: SiLU
+  int out_f32;         // 1: store fp32
+  int convt_co;        // >0: ConvTranspose 2x2/s2 pixel-shuffle store with Co = convt_co
+  const half_t* zero;  // >=16 bytes of zeros in device memory (source for padded taps)
+};
+
+// tile ids for launch_conv_igemm(force_tile)
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3 };
+
+int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s);
+// rows the packed weight buffer must be padded to for a given Cout (multiple of the channel tile)
+int conv_cout_pad(int cout);
+int conv_kpad(int cin, int ksize);
+
+struct StemArgs {
+  const uint8_t* x; int B, H, W;     // uint8 NHWC (B,H,W,3)
+  const float* w;                    // [27][Cout] fp32, already divided by 255
+  const float* bias;                 // [Cout]
+  half_t* y; long y_bstride; int ldy; int Cout;
+};
+int launch_stem(const StemArgs& a, hipStream_t s);
+
+int launch_sppf_pool(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy,
+                     int B, int H, int W, int C, hipStream_t s);
+int launch_upsample2x(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy,
+                      int B, int H, int W, int C, hipStream_t s);
+int launch_head_decode(const float* raw, int B, int in_h, int in_w, int nc, int nm, float* preds,
+                       hipStream_t s);
+int launch_nms(const float* preds, int B, int A, int nc, int nm, float conf, float iou, int max_det,
+               float* dets, int* counts, void* workspace, size_t workspace_bytes, hipStream_t s);
+size_t nms_workspace_bytes(int B, int A);
+int launch_proto_masks(const float* dets, const int* counts, const half_t* protos, int B, int max_det,
+                       int nm, int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s);
+
+}  // namespace m355

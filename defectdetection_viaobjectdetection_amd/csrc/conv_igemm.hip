@@ -1,0 +1,327 @@
+// Implicit-GEMM NHWC fp16 convolution on CDNA4 MFMA (gfx950), fp32 accumulate.
+//
+// Replaces: every Conv2d(+folded BN)+SiLU, the C2f concat write, the
+// Bottleneck residual add and Proto's ConvTranspose2d that upstream reaches through
+// torch.nn.functional.conv2d / conv_transpose2d (call site: BscanBased/yolo8_seg_predict.py:8).
+//
+// GEMM view (roles chosen so that each lane's accumulators are CONSECUTIVE OUTPUT CHANNELS of one
+// pixel, i.e. contiguous NHWC bytes):
+//     D[channel][pixel] = sum_k  W[channel][k] * X[k][pixel],   k = (kh*KS + kw)*Cin + cin
+//   A operand (MFMA rows)  = packed weights  [Cout_pad][Kpad]      (K contiguous)
+//   B operand (MFMA cols)  = im2col gather of the NHWC input       (cin contiguous -> 16-byte chunks)
+// v_mfma_f32_16x16x32_f16: lane l holds A[row l&15][k 8(l>>4)..+7], B[k 8(l>>4)..+7][col l&15],
+// D[row 4(l>>4)+j][col l&15].
+//
+// Data path: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, one 16-byte chunk per
+// lane, per-lane SOURCE address = the im2col gather; padded taps read a zero page), two LDS stages, one
+// barrier per 64-deep K step; LDS rows are 128 B (64 halves) with the 16-byte chunk index XOR-swizzled
+// by (row & 7) -- applied on the source side (which chunk a lane fetches) and on the ds_read side, so
+// the LDS-DMA image stays lane-linear.  ds_read_b128 of a 16-row x 4-chunk fragment is conflict-free.
+//
+// Epilogue: + bias, SiLU, + residual, fp16 pack, 16-byte stores of 8 consecutive channels at a channel
+// offset of a wider NHWC buffer (zero-copy concat); weight rows are permuted by the loader so that
+// lane group g owns channels {g*8..g*8+7} (+32): per store instruction every pixel receives one
+// contiguous 64-byte run.
+#include "common.h"
+
+namespace m355 {
+
+namespace {
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float v) {
+  // v * sigmoid(v);  exp2-based, rcp approx (1 ulp) -- far inside fp16 output rounding
+  float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+  return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// MT/NT: 16x16 MFMA tiles per wave along channels / pixels.  WCH/WPX: waves along channels / pixels.
+template <int MT, int NT, int WCH, int WPX, int KS>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  static_assert(WCH * WPX == 4, "4 waves");
+  constexpr int BCH = WCH * MT * 16;  // channel tile
+  constexpr int BPX = WPX * NT * 16;  // pixel tile
+  constexpr int ROWB = BK * 2;        // 128 bytes per LDS row
+  constexpr int STAGE = (BCH + BPX) * ROWB;
+  constexpr int A_IT = BPX / 32;      // LDS-DMA instructions per wave per stage, activations
+  constexpr int W_IT = BCH / 32;      // weights
+  static_assert(W_IT >= 1 && A_IT >= 1, "tile too small");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- XCD-aware block -> tile map: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
+  // contiguous run of logical tiles, channel tiles fastest, so the tiles that gather the same pixels
+  // (and their halo neighbours) hit the same L2.
+  const int tiles_ch = (a.Cout + BCH - 1) / BCH;
+  const int nwg = gridDim.x;
+  int logical;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tile_ch = logical % tiles_ch;
+  const int tile_px = logical / tiles_ch;
+  const int ch_base = tile_ch * BCH;
+  const int px_base = tile_px * BPX;
+
+  // ---- loader state.  Each lane owns LDS slot (row = 8*i' + lane/8, slot = lane%8) of every
+  // 8-row group it loads; the source chunk for that slot is slot ^ (row & 7) = (lane&7) ^ (lane>>3).
+  const int lrow = lane >> 3;
+  const int cc = (lane & 7) ^ lrow;  // this lane's K-chunk column (8 halves) within a K step
+  const int HoWo = a.Ho * a.Wo;
+
+  long rowoff[A_IT];      // element offset of (b, hi0, wi0, 0) for each of this lane's pixel rows
+  unsigned rowmask[A_IT]; // bit t: tap t is inside the image (and the row is < M)
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int prow = wave * (BPX / 4) + i * 8 + lrow;
+    const int m = px_base + prow;
+    const bool mv = m < a.M;
+    const int mm = mv ? m : 0;
+    const int b = mm / HoWo;
+    const int pix = mm - b * HoWo;
+    const int ho = pix / a.Wo;
+    const int wo = pix - ho * a.Wo;
+    const int hi0 = ho * a.stride - a.pad;
+    const int wi0 = wo * a.stride - a.pad;
+    rowoff[i] = (long)b * a.x_bstride + ((long)hi0 * a.Wi + wi0) * a.ldx;
+    unsigned mk = 0;
+    if (mv) {
+#pragma unroll
+      for (int t = 0; t < KS * KS; ++t) {
+        const int kh = t / KS, kw = t % KS;
+        if ((unsigned)(hi0 + kh) < (unsigned)a.Hi && (unsigned)(wi0 + kw) < (unsigned)a.Wi) mk |= 1u << t;
+      }
+    }
+    rowmask[i] = mk;
+  }
+  // weights: LDS row R (tile-local) holds the weight row of the channel the MFMA row maps to, so
+  // that lane group g ends up owning 8 consecutive channels (see epilogue).  The permutation is applied
+  // on the SOURCE side; LDS rows stay in plain MFMA-tile order (conflict-free ds_read_b128).
+  const half_t* wsrc[W_IT];
+#pragma unroll
+  for (int i = 0; i < W_IT; ++i) {
+    const int R = wave * (BCH / 4) + i * 8 + lrow;
+    const int blk = R / (MT * 16), Rl = R % (MT * 16);
+    const int mt = Rl >> 4, r = Rl & 15;
+    int chl;
+    if (MT >= 2)
+      chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
+    else
+      chl = r;
+    wsrc[i] = a.w + (long)(ch_base + blk * MT * 16 + chl) * a.Kpad + cc * 8;
+  }
+  const float inv_cin = 1.0f / (float)a.Cin;
+
+  auto stage = [&](int t, int buf) {
+    char* sb = smem + buf * STAGE;
+    // weights: rows [wave*BCH/4 + i*8, +8)
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      glds16(wsrc[i] + t * BK, sb + (wave * (BCH / 4) + i * 8) * ROWB);
+    }
+    // activations: tap / cin of this lane's chunk at K step t
+    const int kq = t * BK + cc * 8;
+    int tap, cin;
+    if (KS == 1) {
+      tap = kq >= a.Cin ? 31 : 0;
+      cin = kq;
+    } else {
+      tap = (int)(((float)kq + 0.5f) * inv_cin);
+      cin = kq - tap * a.Cin;
+    }
+    int tapoff;
+    if (KS == 1) {
+      tapoff = cin;
+    } else {
+      const int kh = (tap * 11) >> 5;  // tap/3 for tap < 12
+      const int kw = tap - kh * 3;
+      tapoff = (kh * a.Wi + kw) * a.ldx + cin;
+    }
+    char* ab = sb + BCH * ROWB;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const bool ok = (rowmask[i] >> tap) & 1u;
+      const half_t* src = ok ? (a.x + rowoff[i] + tapoff) : a.zero;
+      glds16(src, ab + (wave * (BPX / 4) + i * 8) * ROWB);
+    }
+  };
+
+  // ---- fragment read addresses (byte offsets inside a stage)
+  const int wch = wave / WPX, wpx = wave % WPX;
+  const int l15 = lane & 15, g = lane >> 4;
+  int aoff[MT];  // weights (A operand): byte offset of (row, chunk g) at ks = 0; ks = 1 is ^ 64
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int r = wch * MT * 16 + mt * 16 + l15;
+    aoff[mt] = r * ROWB + ((g ^ (r & 7)) << 4);
+  }
+  int boff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = wpx * NT * 16 + nt * 16 + l15;
+    boff[nt] = BCH * ROWB + r * ROWB + ((g ^ (r & 7)) << 4);
+  }
+
+  float4v acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = a.Kpad / BK;
+  stage(0, 0);
+  for (int t = 0; t < nk; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
+    const char* sb = smem + (t & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 af[MT], bf[NT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const half8*)(sb + (aoff[mt] ^ (ks << 6)));
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(sb + (boff[nt] ^ (ks << 6)));
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue
+  constexpr int GROUPS = (MT >= 2) ? MT / 2 : 1;  // 8-channel (MT>=2) or 4-channel (MT==1) groups per lane
+  constexpr int GW = (MT >= 2) ? 8 : 4;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int m = px_base + wpx * NT * 16 + nt * 16 + l15;
+    if (m >= a.M) continue;
+    const int b = m / HoWo;
+    const int pix = m - b * HoWo;
+#pragma unroll
+    for (int s = 0; s < GROUPS; ++s) {
+      const int ch0 = ch_base + wch * MT * 16 + ((MT >= 2) ? (s * 32 + g * 8) : (g * 4));
+      if (ch0 >= a.Cout) continue;
+      float v[GW];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (MT >= 2) {
+          v[j] = acc[2 * s][nt][j];
+          v[4 + j] = acc[2 * s + 1][nt][j];
+        } else {
+          v[j] = acc[0][nt][j];
+        }
+      }
+      long yoff;
+      int cidx = ch0;  // bias / output channel index
+      if (a.convt_co > 0) {
+        const int q = ch0 / a.convt_co;
+        cidx = ch0 - q * a.convt_co;
+        const int ho = pix / a.Wo, wo = pix - ho * a.Wo;
+        yoff = (long)b * a.y_bstride + ((long)(2 * ho + (q >> 1)) * (2 * a.Wo) + 2 * wo + (q & 1)) * a.ldy + cidx;
+      } else {
+        yoff = (long)b * a.y_bstride + (long)pix * a.ldy + ch0;
+      }
+#pragma unroll
+      for (int j = 0; j < GW; ++j) v[j] += a.bias[cidx + j];
+      if (a.act) {
+#pragma unroll
+        for (int j = 0; j < GW; ++j) v[j] = silu_f(v[j]);
+      }
+      if (a.res) {
+        const half_t* rp = a.res + (long)b * a.r_bstride + (long)pix * a.ldr + ch0;
+        if (GW == 8) {
+          const half8 rv = *(const half8*)rp;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+        } else {
+          const half4 rv = *(const half4*)rp;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        }
+      }
+      if (a.out_f32) {
+        float* yp = (float*)a.y + yoff;
+#pragma unroll
+        for (int j = 0; j < GW; ++j)
+          if (cidx + j < ((a.convt_co > 0) ? a.convt_co : a.Cout)) yp[j] = v[j];
+      } else {
+        half_t* yp = (half_t*)a.y + yoff;
+        if (GW == 8) {
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+          *(half8*)yp = o;
+        } else {
+          half4 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+          *(half4*)yp = o;
+        }
+      }
+    }
+  }
+}
+
+template <int MT, int NT, int WCH, int WPX>
+int launch_variant(const ConvArgs& a, hipStream_t s) {
+  constexpr int BCH = WCH * MT * 16, BPX = WPX * NT * 16;
+  constexpr int LDS = 2 * (BCH + BPX) * BK * 2;
+  const int tiles_ch = (a.Cout + BCH - 1) / BCH;
+  const int tiles_px = (a.M + BPX - 1) / BPX;
+  const dim3 grid(tiles_ch * tiles_px), block(256);
+  hipError_t e;
+  if (a.ksize == 1) {
+    auto k = conv_igemm_kernel<MT, NT, WCH, WPX, 1>;
+    if (LDS > 65536) {
+      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, grid, block, LDS, s, a);
+  } else {
+    auto k = conv_igemm_kernel<MT, NT, WCH, WPX, 3>;
+    if (LDS > 65536) {
+      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, grid, block, LDS, s, a);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int conv_cout_pad(int cout) { return (cout + 127) / 128 * 128; }
+int conv_kpad(int cin, int ksize) { return (cin * ksize * ksize + BK - 1) / BK * BK; }
+
+int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s) {
+  if (a.ksize != 1 && a.ksize != 3) return -1;
+  if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
+  int tile = force_tile;
+  if (tile < 0) {
+    if (a.Cout > 64)
+      tile = TILE_128x128;
+    else if (a.Cout > 32)
+      tile = TILE_64x128;
+    else
+      tile = TILE_32x256;
+  }
+  switch (tile) {
+    case TILE_128x128: return launch_variant<4, 4, 2, 2>(a, s);
+    case TILE_64x128: return launch_variant<4, 2, 1, 4>(a, s);
+    case TILE_32x256: return launch_variant<2, 4, 1, 4>(a, s);
+    case TILE_64x256: return launch_variant<4, 4, 1, 4>(a, s);
+    default: return -1;
+  }
+}
+
+}  // namespace m355

@@ -1,0 +1,764 @@
+// libmi355yolo.so engine: YOLOv8-seg layer plan, weight packing, workspace and the C-ABI
+// (include/mi355yolo.h).  Host-side C++; all arithmetic is in the HIP kernels of this directory.
+//
+// Graph (upstream yolov8-seg.yaml as exercised by
+// BscanBased/yolo8_seg_predict.py:5-8): every Concat is physical-zero-copy -- producers write their
+// output at a channel offset of the consumer's NHWC buffer; C2f's split/concat is one buffer.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/mi355yolo.h"
+#include "common.h"
+
+using namespace m355;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Tensor {
+  int H = 0, W = 0, C = 0;
+  half_t* p = nullptr;  // (max_batch, H, W, C) fp16 NHWC
+};
+
+struct Slice {  // channel slice of a tensor
+  int t = -1, off = 0, c = 0;
+};
+
+struct ConvLayer {
+  m355_conv_info info{};
+  int Kpad = 0, cout_pad = 0;
+  half_t* w = nullptr;  // packed [cout_pad][Kpad]
+  float* bias = nullptr;
+  bool loaded = false;
+  // fused group: logical convs that were merged into this physical conv (head first-layer fusion)
+};
+
+enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_POOL, OP_UP, OP_DECODE };
+
+struct Op {
+  OpKind kind;
+  int conv = -1;       // physical conv index (phys_)
+  Slice in, out, res;  // tensor slices
+  int out_ext = 0;     // 0: internal tensor; 1: raw head buffer (fp32, anchor offset); 2: protos (caller)
+  int raw_off = 0;     // channel offset in raw buffer
+  int level_off = 0;   // anchor offset of the level in the raw buffer
+  int Hi = 0, Wi = 0;
+};
+
+// A physical conv = what one kernel launch computes.  Usually one logical conv; the three first-layer
+// head convs of a level (cv2/cv3/cv4 .0) share their input and are fused into one launch.
+struct PhysConv {
+  std::vector<int> logical;  // indices into convs_
+  int cin = 0, cout = 0, k = 1, stride = 1, act = 1, transposed = 0;
+  int Kpad = 0, cout_pad = 0;
+  half_t* w = nullptr;
+  float* bias = nullptr;
+  float* stem_w = nullptr;  // stem only: [27][cout] fp32
+};
+
+}  // namespace
+
+struct m355_engine {
+  m355_model_desc desc{};
+  std::string err;
+  std::vector<Tensor> tensors;
+  std::vector<m355_conv_info> convs;   // logical convs (canonical order)
+  std::vector<bool> conv_loaded;
+  std::vector<int> conv_phys;          // logical -> physical
+  std::vector<int> conv_phys_off;      // output-channel offset inside the physical conv
+  std::vector<PhysConv> phys;
+  std::vector<Op> ops;
+  int nc = 1, nm = 32, A = 0, n3 = 0, n4 = 0, n5 = 0;
+  int proto_h = 0, proto_w = 0;
+  float* raw = nullptr;      // (max_batch, A, 64+nc+nm) fp32
+  half_t* zero = nullptr;    // zero page
+  void* nms_ws = nullptr;
+  size_t nms_ws_bytes = 0;
+  size_t ws_bytes = 0;
+  double macs = 0;           // conv MACs per image
+  int feat_in = -1;
+
+  int fail(int code, const std::string& m) {
+    err = m;
+    g_err = m;
+    return code;
+  }
+};
+
+namespace {
+
+#define HIP_TRY(e, call)                                                                            \
+  do {                                                                                              \
+    hipError_t _st = (call);                                                                        \
+    if (_st != hipSuccess)                                                                          \
+      return (e)->fail(M355_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st));           \
+  } while (0)
+
+int make_divisible(double x, int d) { return (int)ceil(x / d) * d; }
+
+struct Builder {
+  m355_engine* e;
+  double depth, width;
+  int maxc;
+  int ch(int c) const { return make_divisible(std::min(c, maxc) * width, 8); }
+  int rep(int n) const { return n > 1 ? std::max((int)lround(n * depth), 1) : n; }
+
+  int tensor(int H, int W, int C) {
+    Tensor t;
+    t.H = H; t.W = W; t.C = C;
+    e->tensors.push_back(t);
+    return (int)e->tensors.size() - 1;
+  }
+  int logical(const std::string& name, int cin, int cout, int k, int s, int has_bn, int transposed, int act) {
+    m355_conv_info ci{};
+    snprintf(ci.name, sizeof(ci.name), "%s", name.c_str());
+    ci.cin = cin; ci.cout = cout; ci.k = k; ci.stride = s; ci.has_bn = has_bn; ci.transposed = transposed;
+    ci.act = act;
+    e->convs.push_back(ci);
+    e->conv_loaded.push_back(false);
+    e->conv_phys.push_back(-1);
+    e->conv_phys_off.push_back(0);
+    return (int)e->convs.size() - 1;
+  }
+  int phys_from(const std::vector<int>& logicals) {
+    PhysConv p;
+    p.logical = logicals;
+    const m355_conv_info& c0 = e->convs[logicals[0]];
+    p.cin = c0.cin; p.k = c0.k; p.stride = c0.stride; p.act = c0.act; p.transposed = c0.transposed;
+    int off = 0;
+    for (int li : logicals) {
+      e->conv_phys[li] = (int)e->phys.size();
+      e->conv_phys_off[li] = off;
+      off += e->convs[li].cout;
+    }
+    p.cout = off;
+    e->phys.push_back(p);
+    return (int)e->phys.size() - 1;
+  }
+  void add_macs(const Op& op, const PhysConv& p) {
+    const Tensor& ti = e->tensors[op.in.t];
+    if (op.kind == OP_CONVT) {
+      e->macs += (double)(2 * ti.H) * (2 * ti.W) * p.cin * p.cout;
+    } else {
+      const int Ho = (ti.H + 2 * (p.k / 2) - p.k) / p.stride + 1, Wo = (ti.W + 2 * (p.k / 2) - p.k) / p.stride + 1;
+      e->macs += (double)Ho * Wo * p.cout * p.cin * p.k * p.k;
+    }
+  }
+  // Conv(+BN+SiLU) from slice `in` to slice `out`
+  void conv(const std::string& name, Slice in, Slice out, int k, int s, Slice res = Slice()) {
+    const int li = logical(name, in.c, out.c, k, s, 1, 0, 1);
+    Op op{};
+    op.kind = OP_CONV;
+    op.conv = phys_from({li});
+    op.in = in; op.out = out; op.res = res;
+    add_macs(op, e->phys[op.conv]);
+    e->ops.push_back(op);
+  }
+  // C2f: in -> out
+  void c2f(const std::string& name, Slice in, Slice out, int n, bool shortcut) {
+    const Tensor& ti = e->tensors[in.t];
+    const int H = ti.H, W = ti.W;
+    const int c = out.c / 2;
+    const int cat = tensor(H, W, (2 + n) * c);
+    conv(name + ".cv1", in, Slice{cat, 0, 2 * c}, 1, 1);
+    for (int j = 0; j < n; ++j) {
+      const int tmp = tensor(H, W, c);
+      const Slice src{cat, (1 + j) * c, c};
+      conv(name + ".m." + std::to_string(j) + ".cv1", src, Slice{tmp, 0, c}, 3, 1);
+      conv(name + ".m." + std::to_string(j) + ".cv2", Slice{tmp, 0, c}, Slice{cat, (2 + j) * c, c}, 3, 1,
+           shortcut ? src : Slice());
+    }
+    conv(name + ".cv2", Slice{cat, 0, (2 + n) * c}, out, 1, 1);
+  }
+};
+
+int build_graph(m355_engine* e) {
+  const m355_model_desc& d = e->desc;
+  Builder b{e, 0, 0, 0};
+  switch (d.scale) {
+    case 'n': b.depth = 0.33; b.width = 0.25; b.maxc = 1024; break;
+    case 's': b.depth = 0.33; b.width = 0.50; b.maxc = 1024; break;
+    case 'm': b.depth = 0.67; b.width = 0.75; b.maxc = 768; break;
+    case 'l': b.depth = 1.00; b.width = 1.00; b.maxc = 512; break;
+    case 'x': b.depth = 1.00; b.width = 1.25; b.maxc = 512; break;
+    default: return e->fail(M355_ERR_INVALID, "scale must be one of n,s,m,l,x");
+  }
+  if (d.in_h % 32 || d.in_w % 32 || d.in_h < 32 || d.in_w < 32)
+    return e->fail(M355_ERR_INVALID, "in_h/in_w must be positive multiples of 32");
+  if (d.nc < 1 || d.max_batch < 1) return e->fail(M355_ERR_INVALID, "nc and max_batch must be >= 1");
+  const int nc = d.nc, nm = 32;
+  e->nc = nc; e->nm = nm;
+  const int c64 = b.ch(64), c128 = b.ch(128), c256 = b.ch(256), c512 = b.ch(512), c1024 = b.ch(1024);
+  const int H = d.in_h, W = d.in_w;
+  const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16,
+            H5 = H / 32, W5 = W / 32;
+  if (c64 != 16 && c64 != 32 && c64 != 48 && c64 != 64 && c64 != 80)
+    return e->fail(M355_ERR_INVALID, "unsupported stem width");
+
+  // concat buffers (zero-copy): cat11=[up(x9), x6] cat14=[up(x12), x4] cat17=[x16, x12] cat20=[x19, x9]
+  const int cat11 = b.tensor(H4, W4, c1024 + c512);
+  const int cat14 = b.tensor(H3, W3, c512 + c256);
+  const int cat17 = b.tensor(H4, W4, c256 + c512);
+  const int cat20 = b.tensor(H5, W5, c512 + c1024);
+  const Slice x4{cat14, c512, c256}, x6{cat11, c1024, c512}, x9{cat20, c512, c1024}, x12{cat17, c256, c512};
+
+  // 0: stem
+  const int t0 = b.tensor(H1, W1, c64);
+  {
+    const int li = b.logical("model.0", 3, c64, 3, 2, 1, 0, 1);
+    Op op{};
+    op.kind = OP_STEM;
+    op.conv = b.phys_from({li});
+    op.out = Slice{t0, 0, c64};
+    op.Hi = H; op.Wi = W;
+    e->macs += (double)H1 * W1 * c64 * 27;
+    e->ops.push_back(op);
+  }
+  const int t1 = b.tensor(H2, W2, c128);
+  b.conv("model.1", Slice{t0, 0, c64}, Slice{t1, 0, c128}, 3, 2);
+  const int t2 = b.tensor(H2, W2, c128);
+  b.c2f("model.2", Slice{t1, 0, c128}, Slice{t2, 0, c128}, b.rep(3), true);
+  const int t3 = b.tensor(H3, W3, c256);
+  b.conv("model.3", Slice{t2, 0, c128}, Slice{t3, 0, c256}, 3, 2);
+  b.c2f("model.4", Slice{t3, 0, c256}, x4, b.rep(6), true);
+  const int t5 = b.tensor(H4, W4, c512);
+  b.conv("model.5", x4, Slice{t5, 0, c512}, 3, 2);
+  b.c2f("model.6", Slice{t5, 0, c512}, x6, b.rep(6), true);
+  const int t7 = b.tensor(H5, W5, c1024);
+  b.conv("model.7", x6, Slice{t7, 0, c1024}, 3, 2);
+  const int t8 = b.tensor(H5, W5, c1024);
+  b.c2f("model.8", Slice{t7, 0, c1024}, Slice{t8, 0, c1024}, b.rep(3), true);
+  // 9: SPPF
+  {
+    const int c_ = c1024 / 2;
+    const int sp = b.tensor(H5, W5, 4 * c_);
+    b.conv("model.9.cv1", Slice{t8, 0, c1024}, Slice{sp, 0, c_}, 1, 1);
+    Op op{};
+    op.kind = OP_POOL;
+    op.in = Slice{sp, 0, c_};
+    op.out = Slice{sp, c_, 3 * c_};
+    e->ops.push_back(op);
+    b.conv("model.9.cv2", Slice{sp, 0, 4 * c_}, x9, 1, 1);
+  }
+  // 10/11: upsample x9 into cat11[0:c1024]
+  {
+    Op op{};
+    op.kind = OP_UP;
+    op.in = x9;
+    op.out = Slice{cat11, 0, c1024};
+    e->ops.push_back(op);
+  }
+  b.c2f("model.12", Slice{cat11, 0, c1024 + c512}, x12, b.rep(3), false);
+  {
+    Op op{};
+    op.kind = OP_UP;
+    op.in = x12;
+    op.out = Slice{cat14, 0, c512};
+    e->ops.push_back(op);
+  }
+  const int t15 = b.tensor(H3, W3, c256);
+  b.c2f("model.15", Slice{cat14, 0, c512 + c256}, Slice{t15, 0, c256}, b.rep(3), false);
+  b.conv("model.16", Slice{t15, 0, c256}, Slice{cat17, 0, c256}, 3, 2);
+  const int t18 = b.tensor(H4, W4, c512);
+  b.c2f("model.18", Slice{cat17, 0, c256 + c512}, Slice{t18, 0, c512}, b.rep(3), false);
+  b.conv("model.19", Slice{t18, 0, c512}, Slice{cat20, 0, c512}, 3, 2);
+  const int t21 = b.tensor(H5, W5, c1024);
+  b.c2f("model.21", Slice{cat20, 0, c512 + c1024}, Slice{t21, 0, c1024}, b.rep(3), false);
+
+  // 22: Segment head
+  const int feats[3] = {t15, t18, t21};
+  const int fch[3] = {c256, c512, c1024};
+  const int hc2 = std::max(std::max(16, fch[0] / 4), 64);
+  const int hc3 = std::max(fch[0], std::min(nc, 100));
+  const int hc4 = std::max(fch[0] / 4, nm);
+  const int npr = b.ch(256);
+  e->n3 = H3 * W3; e->n4 = H4 * W4; e->n5 = H5 * W5;
+  e->A = e->n3 + e->n4 + e->n5;
+  const int lvl_off[3] = {0, e->n3, e->n3 + e->n4};
+  // canonical logical order follows the upstream state dict: cv2.{l}.{0,1,2}, cv3.{l}.*, proto.*, cv4.{l}.*.
+  // Physical fusion: cv2.l.0 + cv3.l.0 + cv4.l.0 share their input -> one launch with cout = hc2+hc3+hc4.
+  int l_cv2[3][3], l_cv3[3][3], l_cv4[3][3];
+  for (int l = 0; l < 3; ++l) {
+    const std::string p = "model.22.cv2." + std::to_string(l);
+    l_cv2[l][0] = b.logical(p + ".0", fch[l], hc2, 3, 1, 1, 0, 1);
+    l_cv2[l][1] = b.logical(p + ".1", hc2, hc2, 3, 1, 1, 0, 1);
+    l_cv2[l][2] = b.logical(p + ".2", hc2, 64, 1, 1, 0, 0, 0);
+  }
+  for (int l = 0; l < 3; ++l) {
+    const std::string p = "model.22.cv3." + std::to_string(l);
+    l_cv3[l][0] = b.logical(p + ".0", fch[l], hc3, 3, 1, 1, 0, 1);
+    l_cv3[l][1] = b.logical(p + ".1", hc3, hc3, 3, 1, 1, 0, 1);
+    l_cv3[l][2] = b.logical(p + ".2", hc3, nc, 1, 1, 0, 0, 0);
+  }
+  const int l_p1 = b.logical("model.22.proto.cv1", fch[0], npr, 3, 1, 1, 0, 1);
+  const int l_pu = b.logical("model.22.proto.upsample", npr, npr, 2, 2, 0, 1, 0);
+  const int l_p2 = b.logical("model.22.proto.cv2", npr, npr, 3, 1, 1, 0, 1);
+  const int l_p3 = b.logical("model.22.proto.cv3", npr, nm, 1, 1, 1, 0, 1);
+  for (int l = 0; l < 3; ++l) {
+    const std::string p = "model.22.cv4." + std::to_string(l);
+    l_cv4[l][0] = b.logical(p + ".0", fch[l], hc4, 3, 1, 1, 0, 1);
+    l_cv4[l][1] = b.logical(p + ".1", hc4, hc4, 3, 1, 1, 0, 1);
+    l_cv4[l][2] = b.logical(p + ".2", hc4, nm, 1, 1, 0, 0, 0);
+  }
+  auto add_conv_op = [&](const std::vector<int>& logicals, Slice in, Slice out, int out_ext, int raw_off,
+                         int level_off, OpKind kind = OP_CONV) {
+    Op op{};
+    op.kind = kind;
+    op.conv = b.phys_from(logicals);
+    op.in = in; op.out = out; op.out_ext = out_ext; op.raw_off = raw_off; op.level_off = level_off;
+    b.add_macs(op, e->phys[op.conv]);
+    e->ops.push_back(op);
+  };
+  const int HW[3][2] = {{H3, W3}, {H4, W4}, {H5, W5}};
+  for (int l = 0; l < 3; ++l) {
+    const int hcat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
+    const Slice f{feats[l], 0, fch[l]};
+    add_conv_op({l_cv2[l][0], l_cv3[l][0], l_cv4[l][0]}, f, Slice{hcat, 0, hc2 + hc3 + hc4}, 0, 0, 0);
+    const int u2 = b.tensor(HW[l][0], HW[l][1], hc2);
+    const int u3 = b.tensor(HW[l][0], HW[l][1], hc3);
+    const int u4 = b.tensor(HW[l][0], HW[l][1], hc4);
+    add_conv_op({l_cv2[l][1]}, Slice{hcat, 0, hc2}, Slice{u2, 0, hc2}, 0, 0, 0);
+    add_conv_op({l_cv3[l][1]}, Slice{hcat, hc2, hc3}, Slice{u3, 0, hc3}, 0, 0, 0);
+    add_conv_op({l_cv4[l][1]}, Slice{hcat, hc2 + hc3, hc4}, Slice{u4, 0, hc4}, 0, 0, 0);
+    add_conv_op({l_cv2[l][2]}, Slice{u2, 0, hc2}, Slice{-1, 0, 64}, 1, 0, lvl_off[l]);
+    add_conv_op({l_cv3[l][2]}, Slice{u3, 0, hc3}, Slice{-1, 0, nc}, 1, 64, lvl_off[l]);
+    add_conv_op({l_cv4[l][2]}, Slice{u4, 0, hc4}, Slice{-1, 0, nm}, 1, 64 + nc, lvl_off[l]);
+  }
+  {
+    const int pr1 = b.tensor(H3, W3, npr), pr2 = b.tensor(H2, W2, npr), pr3 = b.tensor(H2, W2, npr);
+    add_conv_op({l_p1}, Slice{t15, 0, c256}, Slice{pr1, 0, npr}, 0, 0, 0);
+    add_conv_op({l_pu}, Slice{pr1, 0, npr}, Slice{pr2, 0, npr}, 0, 0, 0, OP_CONVT);
+    add_conv_op({l_p2}, Slice{pr2, 0, npr}, Slice{pr3, 0, npr}, 0, 0, 0);
+    add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
+  }
+  {
+    Op op{};
+    op.kind = OP_DECODE;
+    e->ops.push_back(op);
+  }
+  e->proto_h = H2; e->proto_w = W2;
+  return 0;
+}
+
+int alloc_all(m355_engine* e) {
+  const size_t B = (size_t)e->desc.max_batch;
+  size_t total = 0;
+  for (Tensor& t : e->tensors) {
+    const size_t bytes = B * t.H * t.W * t.C * sizeof(half_t);
+    HIP_TRY(e, hipMalloc((void**)&t.p, bytes));
+    total += bytes;
+  }
+  const size_t raw_bytes = B * e->A * (64 + e->nc + e->nm) * sizeof(float);
+  HIP_TRY(e, hipMalloc((void**)&e->raw, raw_bytes));
+  total += raw_bytes;
+  HIP_TRY(e, hipMalloc((void**)&e->zero, 4096));
+  HIP_TRY(e, hipMemset(e->zero, 0, 4096));
+  e->nms_ws_bytes = nms_workspace_bytes((int)B, e->A);
+  HIP_TRY(e, hipMalloc(&e->nms_ws, e->nms_ws_bytes));
+  total += e->nms_ws_bytes + 4096;
+  for (PhysConv& p : e->phys) {
+    const bool stem = (p.cin == 3);
+    if (stem) {
+      HIP_TRY(e, hipMalloc((void**)&p.stem_w, 27 * p.cout * sizeof(float)));
+      HIP_TRY(e, hipMalloc((void**)&p.bias, p.cout * sizeof(float)));
+      total += 28 * p.cout * sizeof(float);
+      continue;
+    }
+    const int cout_v = p.transposed ? 4 * p.cout : p.cout;  // virtual channels of the GEMM
+    p.cout_pad = conv_cout_pad(cout_v);
+    p.Kpad = p.transposed ? conv_kpad(p.cin, 1) : conv_kpad(p.cin, p.k);
+    const size_t wb = (size_t)p.cout_pad * p.Kpad * sizeof(half_t);
+    HIP_TRY(e, hipMalloc((void**)&p.w, wb));
+    HIP_TRY(e, hipMemset(p.w, 0, wb));
+    HIP_TRY(e, hipMalloc((void**)&p.bias, p.cout_pad * sizeof(float)));
+    HIP_TRY(e, hipMemset(p.bias, 0, p.cout_pad * sizeof(float)));
+    total += wb + p.cout_pad * sizeof(float);
+  }
+  e->ws_bytes = total;
+  return 0;
+}
+
+// Pack fp32 (cout,cin,k,k) -> fp16 rows [row0+co][ (kh*k+kw)*cin + ci ] of a [cout_pad][Kpad] matrix.
+void pack_conv_rows(const float* w, int cout, int cin, int k, int Kpad, int row0, std::vector<half_t>& dst) {
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw)
+          dst[(size_t)(row0 + co) * Kpad + (kh * k + kw) * cin + ci] =
+              (half_t)w[(((size_t)co * cin + ci) * k + kh) * k + kw];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* m355_version(void) { return "mi355yolo 0.1 (gfx950, fp16 NHWC implicit-GEMM MFMA)"; }
+
+const char* m355_last_error(const m355_engine* e) { return e ? e->err.c_str() : g_err.c_str(); }
+
+int m355_create(const m355_model_desc* desc, m355_engine** out) {
+  if (!desc || !out) {
+    g_err = "null argument";
+    return M355_ERR_INVALID;
+  }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_err = "no HIP device visible: libmi355yolo has no CPU fallback";
+    return M355_ERR_NO_DEVICE;
+  }
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    g_err = "hipGetDeviceProperties failed";
+    return M355_ERR_HIP;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    g_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+    return M355_ERR_NO_DEVICE;
+  }
+  m355_engine* e = new m355_engine();
+  e->desc = *desc;
+  int rc = build_graph(e);
+  if (rc == 0) rc = alloc_all(e);
+  if (rc != 0) {
+    g_err = e->err;
+    m355_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return M355_OK;
+}
+
+void m355_destroy(m355_engine* e) {
+  if (!e) return;
+  for (Tensor& t : e->tensors)
+    if (t.p) (void)hipFree(t.p);
+  for (PhysConv& p : e->phys) {
+    if (p.w) (void)hipFree(p.w);
+    if (p.bias) (void)hipFree(p.bias);
+    if (p.stem_w) (void)hipFree(p.stem_w);
+  }
+  if (e->raw) (void)hipFree(e->raw);
+  if (e->zero) (void)hipFree(e->zero);
+  if (e->nms_ws) (void)hipFree(e->nms_ws);
+  delete e;
+}
+
+int m355_num_convs(const m355_engine* e) { return e ? (int)e->convs.size() : M355_ERR_INVALID; }
+
+int m355_get_conv_info(const m355_engine* e, int idx, m355_conv_info* out) {
+  if (!e || !out || idx < 0 || idx >= (int)e->convs.size()) return M355_ERR_INVALID;
+  *out = e->convs[idx];
+  return M355_OK;
+}
+
+int m355_num_anchors(const m355_engine* e) { return e ? e->A : M355_ERR_INVALID; }
+int m355_pred_width(const m355_engine* e) { return e ? 4 + e->nc + e->nm : M355_ERR_INVALID; }
+int m355_proto_hw(const m355_engine* e, int* h, int* w) {
+  if (!e || !h || !w) return M355_ERR_INVALID;
+  *h = e->proto_h; *w = e->proto_w;
+  return M355_OK;
+}
+size_t m355_workspace_bytes(const m355_engine* e) { return e ? e->ws_bytes : 0; }
+double m355_flops_per_image(const m355_engine* e) { return e ? 2.0 * e->macs : 0.0; }
+
+int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* bias) {
+  if (!e) return M355_ERR_INVALID;
+  if (!w || !bias || idx < 0 || idx >= (int)e->convs.size()) return e->fail(M355_ERR_INVALID, "bad conv index / null");
+  const m355_conv_info& ci = e->convs[idx];
+  PhysConv& p = e->phys[e->conv_phys[idx]];
+  const int row0 = e->conv_phys_off[idx];
+  if (ci.cin == 3) {  // stem: [27][cout] fp32, scaled by 1/255
+    std::vector<float> sw(27 * ci.cout);
+    for (int co = 0; co < ci.cout; ++co)
+      for (int c = 0; c < 3; ++c)
+        for (int kh = 0; kh < 3; ++kh)
+          for (int kw = 0; kw < 3; ++kw)
+            sw[((kh * 3 + kw) * 3 + c) * ci.cout + co] = w[((co * 3 + c) * 3 + kh) * 3 + kw] * (1.0f / 255.0f);
+    HIP_TRY(e, hipMemcpy(p.stem_w, sw.data(), sw.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(p.bias, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
+  } else if (ci.transposed) {  // (cin,cout,2,2) -> virtual channel (dy*2+dx)*cout + co, K = cin
+    std::vector<half_t> rows((size_t)4 * ci.cout * p.Kpad, (half_t)0.f);
+    for (int c = 0; c < ci.cin; ++c)
+      for (int co = 0; co < ci.cout; ++co)
+        for (int dy = 0; dy < 2; ++dy)
+          for (int dx = 0; dx < 2; ++dx)
+            rows[(size_t)((dy * 2 + dx) * ci.cout + co) * p.Kpad + c] =
+                (half_t)w[(((size_t)c * ci.cout + co) * 2 + dy) * 2 + dx];
+    HIP_TRY(e, hipMemcpy(p.w, rows.data(), rows.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(p.bias, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
+  } else {
+    std::vector<half_t> rows((size_t)ci.cout * p.Kpad, (half_t)0.f);
+    pack_conv_rows(w, ci.cout, ci.cin, ci.k, p.Kpad, 0, rows);
+    HIP_TRY(e, hipMemcpy(p.w + (size_t)row0 * p.Kpad, rows.data(), rows.size() * sizeof(half_t),
+                         hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(p.bias + row0, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
+  }
+  e->conv_loaded[idx] = true;
+  return M355_OK;
+}
+
+int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* d_protos, void* stream) {
+  if (!e) return M355_ERR_INVALID;
+  if (!d_in || !d_preds || !d_protos) return e->fail(M355_ERR_INVALID, "null device pointer");
+  if (B < 1 || B > e->desc.max_batch) return e->fail(M355_ERR_STATE, "batch exceeds max_batch");
+  for (size_t i = 0; i < e->conv_loaded.size(); ++i)
+    if (!e->conv_loaded[i]) return e->fail(M355_ERR_STATE, std::string("weights not set for ") + e->convs[i].name);
+  hipStream_t s = (hipStream_t)stream;
+  const int rw = 64 + e->nc + e->nm;
+  for (const Op& op : e->ops) {
+    int rc = 0;
+    switch (op.kind) {
+      case OP_STEM: {
+        const PhysConv& p = e->phys[op.conv];
+        const Tensor& to = e->tensors[op.out.t];
+        StemArgs a{};
+        a.x = (const uint8_t*)d_in; a.B = B; a.H = op.Hi; a.W = op.Wi;
+        a.w = p.stem_w; a.bias = p.bias;
+        a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C; a.Cout = p.cout;
+        rc = launch_stem(a, s);
+        break;
+      }
+      case OP_CONV:
+      case OP_CONVT: {
+        const PhysConv& p = e->phys[op.conv];
+        const Tensor& ti = e->tensors[op.in.t];
+        ConvArgs a{};
+        a.x = ti.p + op.in.off; a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C;
+        a.Hi = ti.H; a.Wi = ti.W; a.Cin = p.cin;
+        a.w = p.w; a.Kpad = p.Kpad; a.bias = p.bias;
+        a.zero = e->zero;
+        a.act = p.act;
+        if (op.kind == OP_CONVT) {
+          const Tensor& to = e->tensors[op.out.t];
+          a.ksize = 1; a.stride = 1; a.pad = 0;
+          a.Ho = ti.H; a.Wo = ti.W; a.Cout = 4 * p.cout; a.convt_co = p.cout;
+          a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
+        } else {
+          a.ksize = p.k; a.stride = p.stride; a.pad = p.k / 2;
+          a.Ho = (ti.H + 2 * a.pad - p.k) / p.stride + 1;
+          a.Wo = (ti.W + 2 * a.pad - p.k) / p.stride + 1;
+          a.Cout = p.cout;
+          if (op.out_ext == 0) {
+            const Tensor& to = e->tensors[op.out.t];
+            a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
+          } else if (op.out_ext == 1) {
+            a.y = e->raw + (long)op.level_off * rw + op.raw_off;
+            a.y_bstride = (long)e->A * rw; a.ldy = rw; a.out_f32 = 1;
+          } else {
+            a.y = d_protos; a.y_bstride = (long)e->proto_h * e->proto_w * e->nm; a.ldy = e->nm;
+          }
+        }
+        if (op.res.t >= 0) {
+          const Tensor& tr = e->tensors[op.res.t];
+          a.res = tr.p + op.res.off; a.r_bstride = (long)tr.H * tr.W * tr.C; a.ldr = tr.C;
+        }
+        a.M = B * a.Ho * a.Wo;
+        rc = launch_conv_igemm(a, TILE_AUTO, s);
+        break;
+      }
+      case OP_POOL: {
+        const Tensor& t = e->tensors[op.in.t];
+        rc = launch_sppf_pool(t.p + op.in.off, (long)t.H * t.W * t.C, t.C, t.p + op.out.off, (long)t.H * t.W * t.C,
+                              t.C, B, t.H, t.W, op.in.c, s);
+        break;
+      }
+      case OP_UP: {
+        const Tensor& ti = e->tensors[op.in.t];
+        const Tensor& to = e->tensors[op.out.t];
+        rc = launch_upsample2x(ti.p + op.in.off, (long)ti.H * ti.W * ti.C, ti.C, to.p + op.out.off,
+                               (long)to.H * to.W * to.C, to.C, B, ti.H, ti.W, op.in.c, s);
+        break;
+      }
+      case OP_DECODE:
+        rc = launch_head_decode(e->raw, B, e->desc.in_h, e->desc.in_w, e->nc, e->nm, d_preds, s);
+        break;
+    }
+    if (rc != 0) return e->fail(M355_ERR_HIP, "kernel launch failed (op kind " + std::to_string((int)op.kind) +
+                                                  ", code " + std::to_string(rc) + ")");
+  }
+  return M355_OK;
+}
+
+int m355_get_raw_head(m355_engine* e, const float** d_raw, int* width) {
+  if (!e || !d_raw || !width) return M355_ERR_INVALID;
+  *d_raw = e->raw;
+  *width = 64 + e->nc + e->nm;
+  return M355_OK;
+}
+
+int m355_copy_raw_head(m355_engine* e, int B, float* d_out, void* stream) {
+  if (!e) return M355_ERR_INVALID;
+  if (!d_out || B < 1 || B > e->desc.max_batch) return e->fail(M355_ERR_INVALID, "bad argument");
+  const size_t n = (size_t)B * e->A * (64 + e->nc + e->nm) * sizeof(float);
+  HIP_TRY(e, hipMemcpyAsync(d_out, e->raw, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return M355_OK;
+}
+
+int m355_postprocess(m355_engine* e, const float* d_preds, const void* d_protos, int B, float conf, float iou,
+                     int max_det, float* d_dets, int* d_counts, uint8_t* d_masks, void* stream) {
+  if (!e) return M355_ERR_INVALID;
+  if (!d_preds || !d_dets || !d_counts) return e->fail(M355_ERR_INVALID, "null device pointer");
+  if (B < 1 || B > e->desc.max_batch) return e->fail(M355_ERR_STATE, "batch exceeds max_batch");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = launch_nms(d_preds, B, e->A, e->nc, e->nm, conf, iou, max_det, d_dets, d_counts, e->nms_ws,
+                      e->nms_ws_bytes, s);
+  if (rc != 0) return e->fail(M355_ERR_HIP, "nms launch failed: " + std::to_string(rc));
+  if (d_masks) {
+    if (!d_protos) return e->fail(M355_ERR_INVALID, "d_protos is null");
+    rc = launch_proto_masks(d_dets, d_counts, (const half_t*)d_protos, B, max_det, e->nm, e->proto_h, e->proto_w,
+                            e->desc.in_h, e->desc.in_w, d_masks, s);
+    if (rc != 0) return e->fail(M355_ERR_HIP, "mask launch failed: " + std::to_string(rc));
+  }
+  return M355_OK;
+}
+
+// ------------------------------- per-op entry points (unit parity) -------------------------------
+
+static int set_err(int code, const std::string& m) {
+  g_err = m;
+  return code;
+}
+#define HIP_TRYG(call)                                                                                \
+  do {                                                                                                \
+    hipError_t _st = (call);                                                                          \
+    if (_st != hipSuccess) return set_err(M355_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(_st)); \
+  } while (0)
+
+static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const float* h_w, const float* h_bias,
+                          int cout, int k, int stride, int act, const void* d_res, void* d_y, int out_f32,
+                          int force_tile, int transposed, void* stream) {
+  if (!d_x || !h_w || !h_bias || !d_y) return set_err(M355_ERR_INVALID, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  const int cout_v = transposed ? 4 * cout : cout;
+  const int cout_pad = conv_cout_pad(cout_v);
+  const int Kpad = transposed ? conv_kpad(cin, 1) : conv_kpad(cin, k);
+  std::vector<half_t> rows((size_t)cout_pad * Kpad, (half_t)0.f);
+  std::vector<float> bias(cout_pad, 0.f);
+  if (transposed) {
+    for (int c = 0; c < cin; ++c)
+      for (int co = 0; co < cout; ++co)
+        for (int dy = 0; dy < 2; ++dy)
+          for (int dx = 0; dx < 2; ++dx)
+            rows[(size_t)((dy * 2 + dx) * cout + co) * Kpad + c] = (half_t)h_w[(((size_t)c * cout + co) * 2 + dy) * 2 + dx];
+  } else {
+    pack_conv_rows(h_w, cout, cin, k, Kpad, 0, rows);
+  }
+  for (int i = 0; i < cout; ++i) bias[i] = h_bias[i];
+  half_t *dw = nullptr, *dz = nullptr;
+  float* db = nullptr;
+  HIP_TRYG(hipMalloc((void**)&dw, rows.size() * sizeof(half_t)));
+  HIP_TRYG(hipMalloc((void**)&db, bias.size() * sizeof(float)));
+  HIP_TRYG(hipMalloc((void**)&dz, 256));
+  HIP_TRYG(hipMemset(dz, 0, 256));
+  HIP_TRYG(hipMemcpy(dw, rows.data(), rows.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  ConvArgs a{};
+  a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * cin; a.ldx = cin; a.Hi = H; a.Wi = W; a.Cin = cin;
+  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = act; a.out_f32 = out_f32;
+  a.y = d_y;
+  if (transposed) {
+    a.ksize = 1; a.stride = 1; a.pad = 0; a.Ho = H; a.Wo = W; a.Cout = 4 * cout; a.convt_co = cout;
+    a.y_bstride = (long)4 * H * W * cout; a.ldy = cout;
+  } else {
+    a.ksize = k; a.stride = stride; a.pad = k / 2;
+    a.Ho = (H + 2 * a.pad - k) / stride + 1; a.Wo = (W + 2 * a.pad - k) / stride + 1; a.Cout = cout;
+    a.y_bstride = (long)a.Ho * a.Wo * cout; a.ldy = cout;
+    if (d_res) { a.res = (const half_t*)d_res; a.r_bstride = a.y_bstride; a.ldr = cout; }
+  }
+  a.M = B * a.Ho * a.Wo;
+  const int rc = launch_conv_igemm(a, force_tile, s);
+  hipError_t se = hipStreamSynchronize(s);
+  (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dz);
+  if (rc != 0) return set_err(M355_ERR_HIP, "conv launch failed: " + std::to_string(rc));
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("conv kernel: ") + hipGetErrorString(se));
+  return M355_OK;
+}
+
+int m355_conv2d_fwd(const void* d_x, int B, int H, int W, int cin, const float* h_w, const float* h_bias, int cout,
+                    int k, int stride, int act, const void* d_res, void* d_y, int out_f32, int force_tile,
+                    void* stream) {
+  return conv_op_common(d_x, B, H, W, cin, h_w, h_bias, cout, k, stride, act, d_res, d_y, out_f32, force_tile, 0,
+                        stream);
+}
+
+int m355_convt2x2_fwd(const void* d_x, int B, int H, int W, int cin, const float* h_w, const float* h_bias, int cout,
+                      void* d_y, void* stream) {
+  return conv_op_common(d_x, B, H, W, cin, h_w, h_bias, cout, 2, 2, 0, nullptr, d_y, 0, TILE_AUTO, 1, stream);
+}
+
+int m355_stem_fwd(const void* d_in, int B, int H, int W, const float* h_w, const float* h_bias, int cout, void* d_y,
+                  void* stream) {
+  if (!d_in || !h_w || !h_bias || !d_y) return set_err(M355_ERR_INVALID, "null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<float> sw(27 * cout);
+  for (int co = 0; co < cout; ++co)
+    for (int c = 0; c < 3; ++c)
+      for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw)
+          sw[((kh * 3 + kw) * 3 + c) * cout + co] = h_w[((co * 3 + c) * 3 + kh) * 3 + kw] * (1.0f / 255.0f);
+  float *dw = nullptr, *db = nullptr;
+  HIP_TRYG(hipMalloc((void**)&dw, sw.size() * sizeof(float)));
+  HIP_TRYG(hipMalloc((void**)&db, cout * sizeof(float)));
+  HIP_TRYG(hipMemcpy(dw, sw.data(), sw.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(db, h_bias, cout * sizeof(float), hipMemcpyHostToDevice));
+  StemArgs a{};
+  a.x = (const uint8_t*)d_in; a.B = B; a.H = H; a.W = W; a.w = dw; a.bias = db;
+  a.y = (half_t*)d_y; a.y_bstride = (long)(H / 2) * (W / 2) * cout; a.ldy = cout; a.Cout = cout;
+  const int rc = launch_stem(a, s);
+  hipError_t se = hipStreamSynchronize(s);
+  (void)hipFree(dw); (void)hipFree(db);
+  if (rc != 0) return set_err(M355_ERR_HIP, "stem launch failed: " + std::to_string(rc));
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("stem kernel: ") + hipGetErrorString(se));
+  return M355_OK;
+}
+
+int m355_sppf_pool(const void* d_x, int B, int H, int W, int C, void* d_y, void* stream) {
+  if (!d_x || !d_y) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_sppf_pool((const half_t*)d_x, (long)H * W * C, C, (half_t*)d_y, (long)H * W * 3 * C, 3 * C, B,
+                                  H, W, C, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "sppf launch failed: " + std::to_string(rc));
+}
+
+int m355_upsample2x(const void* d_x, int B, int H, int W, int C, void* d_y, void* stream) {
+  if (!d_x || !d_y) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_upsample2x((const half_t*)d_x, (long)H * W * C, C, (half_t*)d_y, (long)4 * H * W * C, C, B, H,
+                                   W, C, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "upsample launch failed: " + std::to_string(rc));
+}
+
+int m355_head_decode(const float* d_raw, int B, int in_h, int in_w, int nc, float* d_preds, void* stream) {
+  if (!d_raw || !d_preds) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_head_decode(d_raw, B, in_h, in_w, nc, 32, d_preds, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "decode launch failed: " + std::to_string(rc));
+}
+
+int m355_nms(const float* d_preds, int B, int A, int nc, int nm, float conf, float iou, int max_det, float* d_dets,
+             int* d_counts, void* stream) {
+  if (!d_preds || !d_dets || !d_counts) return set_err(M355_ERR_INVALID, "null pointer");
+  void* ws = nullptr;
+  const size_t wsb = nms_workspace_bytes(B, A);
+  HIP_TRYG(hipMalloc(&ws, wsb));
+  const int rc = launch_nms(d_preds, B, A, nc, nm, conf, iou, max_det, d_dets, d_counts, ws, wsb, (hipStream_t)stream);
+  hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+  (void)hipFree(ws);
+  if (rc != 0) return set_err(M355_ERR_HIP, "nms launch failed: " + std::to_string(rc));
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("nms kernel: ") + hipGetErrorString(se));
+  return M355_OK;
+}
+
+int m355_proto_masks(const float* d_dets, const int* d_counts, const void* d_protos, int B, int max_det, int mh,
+                     int mw, int in_h, int in_w, uint8_t* d_masks, void* stream) {
+  if (!d_dets || !d_counts || !d_protos || !d_masks) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_proto_masks(d_dets, d_counts, (const half_t*)d_protos, B, max_det, 32, mh, mw, in_h, in_w,
+                                    d_masks, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "mask launch failed: " + std::to_string(rc));
+}
+
+}  // extern "C"

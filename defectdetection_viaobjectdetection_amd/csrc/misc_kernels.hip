@@ -1,0 +1,235 @@
+// HBM-bound kernels of the YOLOv8-seg forward: stem conv (uint8 -> fp16), SPPF pooling, nearest 2x
+// upsample into a concat slice, and the Detect decode (DFL softmax-expectation + dist2bbox + sigmoid).
+// Replaces upstream aten ops reached from SegmentationModel.forward (SURVEY.md A3/A7/A8/A9;
+// call site BscanBased/yolo8_seg_predict.py:8).
+#include "common.h"
+
+namespace m355 {
+namespace {
+
+__device__ __forceinline__ float silu_f(float v) {
+  float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+  return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem: 3x3 stride-2 pad-1 conv on uint8 NHWC (B,H,W,3) -> fp16 NHWC (B,H/2,W/2,COUT), + bias + SiLU.
+// K = 27 is too short for the LDS-DMA implicit GEMM; the layer is HBM-bound (1.2 MB in, COUT*0.2 MB
+// out per 640x640 image), so one thread computes one output pixel for all COUT channels on the VALU
+// with wave-uniform weights (scalar loads).  Weights already hold the 1/255 input scaling.
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
+  const int Ho = a.H >> 1, Wo = a.W >> 1;
+  const long total = (long)a.B * Ho * Wo;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int b = (int)(idx / (Ho * Wo));
+  const int pix = (int)(idx - (long)b * Ho * Wo);
+  const int ho = pix / Wo, wo = pix - ho * Wo;
+  float acc[COUT];
+#pragma unroll
+  for (int c = 0; c < COUT; ++c) acc[c] = a.bias[c];
+  const uint8_t* xb = a.x + (long)b * a.H * a.W * 3;
+#pragma unroll
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = 2 * ho - 1 + kh;
+    const bool hv = (unsigned)hi < (unsigned)a.H;
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = 2 * wo - 1 + kw;
+      const bool v = hv && (unsigned)wi < (unsigned)a.W;
+      const uint8_t* p = xb + ((long)hi * a.W + wi) * 3;
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float xv = v ? (float)p[ci] : 0.f;
+        const float* wr = a.w + ((kh * 3 + kw) * 3 + ci) * COUT;
+#pragma unroll
+        for (int c = 0; c < COUT; ++c) acc[c] = __builtin_fmaf(xv, wr[c], acc[c]);
+      }
+    }
+  }
+  half_t* yp = a.y + (long)b * a.y_bstride + (long)pix * a.ldy;
+#pragma unroll
+  for (int c0 = 0; c0 < COUT; c0 += 8) {
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)silu_f(acc[c0 + j]);
+    *(half8*)(yp + c0) = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SPPF pooling: y[:, 0:C] = mp5(x), y[:, C:2C] = mp5(mp5(x)), y[:, 2C:3C] = mp5^3(x)  (5x5, s1, p2,
+// -inf padding == clipped windows).  One block per (image, 8-channel group); the whole HxW plane of
+// 8 channels sits in LDS (6.4 KB at 20x20) and the three pools run back to back from LDS.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
+  half8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = a[j] > b[j] ? a[j] : b[j];
+  return r;
+}
+
+__global__ __launch_bounds__(256) void sppf_pool_kernel(const half_t* x, long x_bstride, int ldx, half_t* y,
+                                                        long y_bstride, int ldy, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  half8* p0 = (half8*)smem;
+  half8* p1 = p0 + H * W;
+  const int groups = C / 8;
+  const int b = blockIdx.x / groups, gq = blockIdx.x % groups;
+  const half_t* xb = x + (long)b * x_bstride + gq * 8;
+  half_t* yb = y + (long)b * y_bstride + gq * 8;
+  const int n = H * W;
+  for (int i = threadIdx.x; i < n; i += 256) p0[i] = *(const half8*)(xb + (long)i * ldx);
+  __syncthreads();
+  half8* src = p0;
+  half8* dst = p1;
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int h = i / W, w = i - h * W;
+      const int h0 = h - 2 < 0 ? 0 : h - 2, h1 = h + 2 >= H ? H - 1 : h + 2;
+      const int w0 = w - 2 < 0 ? 0 : w - 2, w1 = w + 2 >= W ? W - 1 : w + 2;
+      half8 m = src[h0 * W + w0];
+      for (int hh = h0; hh <= h1; ++hh)
+        for (int ww = w0; ww <= w1; ++ww) m = hmax8(m, src[hh * W + ww]);
+      dst[i] = m;
+      *(half8*)(yb + (long)i * ldy + lvl * C) = m;
+    }
+    __syncthreads();
+    half8* t = src;
+    src = dst;
+    dst = t;
+  }
+}
+
+// Nearest 2x upsample of an NHWC slice into another NHWC slice (16-byte chunks).
+__global__ __launch_bounds__(256) void upsample2x_kernel(const half_t* x, long x_bstride, int ldx, half_t* y,
+                                                         long y_bstride, int ldy, int B, int H, int W, int C) {
+  const int cg = C / 8;
+  const long total = (long)B * 2 * H * 2 * W * cg;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (int)(idx % cg);
+    long r = idx / cg;
+    const int wo = (int)(r % (2 * W));
+    r /= 2 * W;
+    const int ho = (int)(r % (2 * H));
+    const int b = (int)(r / (2 * H));
+    const half8 v = *(const half8*)(x + (long)b * x_bstride + ((long)(ho >> 1) * W + (wo >> 1)) * ldx + c * 8);
+    *(half8*)(y + (long)b * y_bstride + ((long)ho * 2 * W + wo) * ldy + c * 8) = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Detect decode (A9).  raw (B,A,64+nc+nm) f32 -> preds (B,A,4+nc+nm) f32.
+// Four lanes per anchor: lane q computes side q's DFL expectation (softmax over 16 bins . arange(16)),
+// the quad exchanges l,t,r,b by DPP-class shuffles, lane q writes output q of (cx,cy,w,h)*stride, and
+// the quad copies sigmoid(cls) and the mask coefficients.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void head_decode_kernel(const float* raw, int B, int A, int w3, int w4, int w5,
+                                                          int n3, int n4, int nc, int nm, float* preds) {
+  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
+  const long anchor_g = gid >> 2;
+  const int q = (int)(gid & 3);
+  const bool valid = anchor_g < (long)B * A;
+  const long ag = valid ? anchor_g : 0;
+  const int a = (int)(ag % A);
+  const int wi = 64 + nc + nm, wo = 4 + nc + nm;
+  const float* rp = raw + ag * wi;
+  // DFL: softmax-expectation over this side's 16 logits
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = rp[q * 16 + j];
+  float mx = v[0];
+#pragma unroll
+  for (int j = 1; j < 16; ++j) mx = fmaxf(mx, v[j]);
+  float se = 0.f, sw = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float e = __expf(v[j] - mx);
+    se += e;
+    sw += e * (float)j;
+  }
+  const float d = sw / se;
+  // anchor point and stride
+  int al = a, gw = w3;
+  float stride = 8.f;
+  if (a >= n3 + n4) {
+    al = a - n3 - n4; gw = w5; stride = 32.f;
+  } else if (a >= n3) {
+    al = a - n3; gw = w4; stride = 16.f;
+  }
+  const int gy = al / gw, gx = al - gy * gw;
+  const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+  const int lbase = (threadIdx.x & 63) & ~3;
+  const float dl = __shfl(d, lbase + 0), dt = __shfl(d, lbase + 1), dr = __shfl(d, lbase + 2),
+              db = __shfl(d, lbase + 3);
+  const float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;
+  float o;
+  if (q == 0) o = (x1 + x2) * 0.5f;
+  else if (q == 1) o = (y1 + y2) * 0.5f;
+  else if (q == 2) o = x2 - x1;
+  else o = y2 - y1;
+  if (!valid) return;
+  float* pp = preds + ag * wo;
+  pp[q] = o * stride;
+  for (int j = q; j < nc; j += 4) {
+    const float z = rp[64 + j];
+    pp[4 + j] = 1.0f / (1.0f + __expf(-z));
+  }
+  for (int j = q; j < nm; j += 4) pp[4 + nc + j] = rp[64 + nc + j];
+}
+
+}  // namespace
+
+int launch_stem(const StemArgs& a, hipStream_t s) {
+  const long total = (long)a.B * (a.H / 2) * (a.W / 2);
+  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  switch (a.Cout) {
+    case 16: hipLaunchKernelGGL(stem_kernel<16>, grid, block, 0, s, a); break;
+    case 32: hipLaunchKernelGGL(stem_kernel<32>, grid, block, 0, s, a); break;
+    case 48: hipLaunchKernelGGL(stem_kernel<48>, grid, block, 0, s, a); break;
+    case 64: hipLaunchKernelGGL(stem_kernel<64>, grid, block, 0, s, a); break;
+    case 80: hipLaunchKernelGGL(stem_kernel<80>, grid, block, 0, s, a); break;
+    default: return -1;
+  }
+  return (int)hipGetLastError();
+}
+
+int launch_sppf_pool(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy, int B, int H,
+                     int W, int C, hipStream_t s) {
+  if (C % 8 || ldx % 8 || ldy % 8) return -1;
+  const size_t lds = (size_t)2 * H * W * 16;
+  if (lds > 160 * 1024) return -1;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute((const void*)sppf_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(sppf_pool_kernel, dim3(B * (C / 8)), dim3(256), lds, s, x, x_bstride, ldx, y, y_bstride, ldy,
+                     H, W, C);
+  return (int)hipGetLastError();
+}
+
+int launch_upsample2x(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy, int B, int H,
+                      int W, int C, hipStream_t s) {
+  if (C % 8 || ldx % 8 || ldy % 8) return -1;
+  const long total = (long)B * 4 * H * W * (C / 8);
+  long blocks = (total + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(upsample2x_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, x_bstride, ldx, y, y_bstride,
+                     ldy, B, H, W, C);
+  return (int)hipGetLastError();
+}
+
+int launch_head_decode(const float* raw, int B, int in_h, int in_w, int nc, int nm, float* preds, hipStream_t s) {
+  const int h3 = in_h / 8, w3 = in_w / 8, h4 = in_h / 16, w4 = in_w / 16, h5 = in_h / 32, w5 = in_w / 32;
+  const int n3 = h3 * w3, n4 = h4 * w4, n5 = h5 * w5;
+  const int A = n3 + n4 + n5;
+  const long threads = (long)B * A * 4;
+  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, raw, B, A, w3,
+                     w4, w5, n3, n4, nc, nm, preds);
+  return (int)hipGetLastError();
+}
+
+}  // namespace m355

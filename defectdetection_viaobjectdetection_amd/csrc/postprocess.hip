@@ -1,0 +1,272 @@
+// Post-processing of the YOLOv8-seg head on gfx950: batched NMS (A11) and mask assembly (A12).
+// Replaces upstream utils.ops.non_max_suppression / process_mask / crop_mask reached from
+// SegmentationPredictor.postprocess (call site BscanBased/yolo8_seg_predict.py:8).
+//
+// This file is compiled with -ffp-contract=off: the IoU / box arithmetic must round exactly like the
+// oracle's float32 numpy ops so that the NMS keep-set is bit-exact for identical inputs.
+#include "common.h"
+
+namespace m355 {
+namespace {
+
+constexpr int NMS_THREADS = 1024;
+constexpr int MAX_KEEP = 1024;      // upper bound for max_det
+constexpr float MAX_WH = 7680.0f;   // class offset (non-agnostic NMS)
+
+struct Box { float x1, y1, x2, y2; };
+
+__device__ __forceinline__ float iou_f32(const Box& a, const Box& b) {
+  const float area_a = (a.x2 - a.x1) * (a.y2 - a.y1);
+  const float area_b = (b.x2 - b.x1) * (b.y2 - b.y1);
+  const float w = fmaxf(0.f, fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1));
+  const float h = fmaxf(0.f, fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1));
+  const float inter = w * h;
+  const float uni = (area_a + area_b) - inter;
+  return inter / uni;
+}
+
+// One 1024-thread block per image.
+//  1. candidates: conf = max_c score > thr; key = (conf bits << 32) | (0xFFFFFFFF - anchor)  -> sorting
+//     keys descending gives confidence descending, ties by lower anchor index first (oracle order).
+//  2. bitonic sort of the keys in LDS (n padded to a power of two; <= 16384 keys = 128 KB) or, for
+//     larger anchor counts, in the global workspace.
+//  3. wave 0 runs greedy NMS over 64-candidate chunks: each lane owns one candidate, tests it against
+//     the kept list (LDS broadcast), then the chunk is resolved in order with ballot/ffs.
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, int A, int nc, int nm, float conf_thr,
+                                                          float iou_thr, int max_det, float* dets, int* counts,
+                                                          unsigned long long* gkeys, int keys_in_lds,
+                                                          int npad_max) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  // layout: [kept boxes MAX_KEEP*16][kept idx MAX_KEEP*4][misc 16][keys ...]
+  Box* kbox = (Box*)smem;
+  int* kidx = (int*)(smem + MAX_KEEP * 16);
+  int* misc = (int*)(smem + MAX_KEEP * 20);
+  unsigned long long* keys =
+      keys_in_lds ? (unsigned long long*)(smem + MAX_KEEP * 20 + 16) : gkeys + (long)blockIdx.x * npad_max;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int wd = 4 + nc + nm;
+  const float* pb = preds + (long)b * A * wd;
+
+  if (tid == 0) misc[0] = 0;
+  __syncthreads();
+  for (int a = tid; a < A; a += NMS_THREADS) {
+    const float* p = pb + (long)a * wd + 4;
+    float best = p[0];
+    for (int c = 1; c < nc; ++c) best = fmaxf(best, p[c]);
+    if (best > conf_thr) {
+      const int slot = atomicAdd(&misc[0], 1);
+      keys[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)a);
+    }
+  }
+  __syncthreads();
+  const int n = misc[0];
+  int npad = 1;
+  while (npad < n) npad <<= 1;
+  for (int i = n + tid; i < npad; i += NMS_THREADS) keys[i] = 0ull;
+  __syncthreads();
+  // bitonic sort, descending
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < npad; i += NMS_THREADS) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const unsigned long long x = keys[i], y = keys[ixj];
+          const bool desc = (i & k) == 0;
+          if (desc ? (x < y) : (x > y)) {
+            keys[i] = y;
+            keys[ixj] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // greedy NMS by wave 0
+  if (tid < 64) {
+    const int lane = tid;
+    int kept = 0;
+    const int nchunks = (n + 63) >> 6;
+    for (int c = 0; c < nchunks && kept < max_det; ++c) {
+      const int i = c * 64 + lane;
+      const bool valid = i < n;
+      int anchor = 0;
+      Box bx = {0.f, 0.f, 0.f, 0.f};
+      if (valid) {
+        anchor = (int)(0xFFFFFFFFu - (unsigned)(keys[i] & 0xFFFFFFFFull));
+        const float* p = pb + (long)anchor * wd;
+        const float cx = p[0], cy = p[1], hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+        int cls = 0;
+        float best = p[4];
+        for (int cc = 1; cc < nc; ++cc)
+          if (p[4 + cc] > best) { best = p[4 + cc]; cls = cc; }
+        const float off = (float)cls * MAX_WH;
+        bx.x1 = (cx - hw) + off; bx.y1 = (cy - hh) + off; bx.x2 = (cx + hw) + off; bx.y2 = (cy + hh) + off;
+      }
+      bool alive = valid;
+      for (int k = 0; k < kept; ++k) {
+        const Box kb = kbox[k];
+        if (alive && iou_f32(kb, bx) > iou_thr) alive = false;
+      }
+      unsigned long long mask = __ballot(alive);
+      while (mask) {
+        const int j = __ffsll((long long)mask) - 1;
+        Box jb;
+        jb.x1 = __shfl(bx.x1, j); jb.y1 = __shfl(bx.y1, j); jb.x2 = __shfl(bx.x2, j); jb.y2 = __shfl(bx.y2, j);
+        if (lane == j) { kbox[kept] = bx; kidx[kept] = anchor; }
+        ++kept;
+        if (kept >= max_det) break;
+        if (lane > j && alive && iou_f32(jb, bx) > iou_thr) alive = false;
+        const unsigned long long above = (j == 63) ? 0ull : (~0ull << (j + 1));
+        mask = __ballot(alive) & above;
+      }
+    }
+    if (lane == 0) { misc[1] = kept; counts[b] = kept; }
+  }
+  __syncthreads();
+  // emit rows [x1,y1,x2,y2,conf,cls,coefs...]
+  const int kept = misc[1];
+  const int ow = 6 + nm;
+  for (int idx = tid; idx < kept * ow; idx += NMS_THREADS) {
+    const int k = idx / ow, f = idx - k * ow;
+    const int anchor = kidx[k];
+    const float* p = pb + (long)anchor * wd;
+    float v;
+    if (f < 4) {
+      const float cx = p[0], cy = p[1], hw = p[2] / 2.0f, hh = p[3] / 2.0f;
+      v = f == 0 ? cx - hw : f == 1 ? cy - hh : f == 2 ? cx + hw : cy + hh;
+    } else if (f < 6) {
+      int cls = 0;
+      float best = p[4];
+      for (int cc = 1; cc < nc; ++cc)
+        if (p[4 + cc] > best) { best = p[4 + cc]; cls = cc; }
+      v = f == 4 ? best : (float)cls;
+    } else {
+      v = p[4 + nc + (f - 6)];
+    }
+    dets[((long)b * max_det + k) * ow + f] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Mask assembly (A12): for detection k of image b and one 16x16 tile of the prototype grid:
+//   logits(y,x) = sum_c coef[c] * proto[y][x][c]      on the tile + 1-pixel halo (18x18), in LDS
+//   zero outside the box scaled to the prototype grid (x1 <= col < x2, y1 <= row < y2)
+//   bilinear upsample x(in/mh) with align_corners=False  -> 64x64 output pixels, mask = value > 0
+// One 256-thread block; each thread emits 16 consecutive output pixels (one 16-byte store).
+// NM prototypes (32) * fp16 = one 64-byte NHWC pixel.
+// ---------------------------------------------------------------------------------------------
+template <int NM>
+__global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, const int* counts, const half_t* protos,
+                                                          int max_det, int mh, int mw, int in_h, int in_w,
+                                                          uint8_t* masks) {
+  const int b = blockIdx.z, k = blockIdx.y;
+  if (k >= counts[b]) return;
+  const int tiles_x = (mw + 15) / 16;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  __shared__ float lg[18][19];
+  __shared__ float coef[NM];
+  const float* d = dets + ((long)b * max_det + k) * (6 + NM);
+  if (threadIdx.x < NM) coef[threadIdx.x] = d[6 + threadIdx.x];
+  const float wr = (float)mw / (float)in_w, hr = (float)mh / (float)in_h;
+  const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
+  __syncthreads();
+  const half_t* pb = protos + (long)b * mh * mw * NM;
+  for (int i = threadIdx.x; i < 18 * 18; i += 256) {
+    const int ly = i / 18, lx = i - ly * 18;
+    const int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
+    float v = 0.f;
+    if (y >= 0 && y < mh && x >= 0 && x < mw) {
+      const float xf = (float)x, yf = (float)y;
+      if (xf >= bx1 && xf < bx2 && yf >= by1 && yf < by2) {
+        const half8* pp = (const half8*)(pb + ((long)y * mw + x) * NM);
+        float s = 0.f;
+#pragma unroll
+        for (int c8 = 0; c8 < NM / 8; ++c8) {
+          const half8 h = pp[c8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += coef[c8 * 8 + j] * (float)h[j];
+        }
+        v = s;
+      }
+    }
+    lg[ly][lx] = v;
+  }
+  __syncthreads();
+  const int up_y = in_h / mh, up_x = in_w / mw;  // 4
+  const float sy = (float)mh / (float)in_h, sx = (float)mw / (float)in_w;
+  const int out_w = 16 * up_x, out_h = 16 * up_y;  // 64 x 64 per tile
+  const int segs = out_w / 16;
+  for (int i = threadIdx.x; i < out_h * segs; i += 256) {
+    const int oy = i / segs, seg = i - oy * segs;
+    const int Y = ty * out_h + oy;
+    if (Y >= in_h) continue;
+    float fy = sy * ((float)Y + 0.5f) - 0.5f;
+    if (fy < 0.f) fy = 0.f;
+    const int y0 = (int)fy;
+    const int y1 = y0 < mh - 1 ? y0 + 1 : y0;
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const int r0 = y0 - (ty * 16 - 1), r1 = y1 - (ty * 16 - 1);
+    uint8_t o[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int X = tx * out_w + seg * 16 + j;
+      float fx = sx * ((float)X + 0.5f) - 0.5f;
+      if (fx < 0.f) fx = 0.f;
+      const int x0 = (int)fx;
+      const int x1 = x0 < mw - 1 ? x0 + 1 : x0;
+      const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+      const int c0 = x0 - (tx * 16 - 1), c1 = x1 - (tx * 16 - 1);
+      const float v = ly0 * (lx0 * lg[r0][c0] + lx1 * lg[r0][c1]) + ly1 * (lx0 * lg[r1][c0] + lx1 * lg[r1][c1]);
+      o[j] = v > 0.f ? 1 : 0;
+    }
+    const int X0 = tx * out_w + seg * 16;
+    uint8_t* mp = masks + (((long)b * max_det + k) * in_h + Y) * in_w + X0;
+    if (X0 + 16 <= in_w) {
+      *(uint4*)mp = *(const uint4*)o;
+    } else {
+      for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = o[j];
+    }
+  }
+}
+
+}  // namespace
+
+size_t nms_workspace_bytes(int B, int A) {
+  int npad = 1;
+  while (npad < A) npad <<= 1;
+  return (size_t)B * npad * 8;
+}
+
+int launch_nms(const float* preds, int B, int A, int nc, int nm, float conf, float iou, int max_det, float* dets,
+               int* counts, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  if (max_det > MAX_KEEP || max_det < 1) return -1;
+  int npad = 1;
+  while (npad < A) npad <<= 1;
+  const size_t base = MAX_KEEP * 20 + 16;
+  const bool in_lds = base + (size_t)npad * 8 <= 160 * 1024 - 256;
+  if (!in_lds && workspace_bytes < (size_t)B * npad * 8) return -1;
+  const size_t lds = in_lds ? base + (size_t)npad * 8 : base;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024 - 256);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, s, preds, A, nc, nm, conf, iou, max_det, dets,
+                     counts, (unsigned long long*)workspace, in_lds ? 1 : 0, npad);
+  return (int)hipGetLastError();
+}
+
+int launch_proto_masks(const float* dets, const int* counts, const half_t* protos, int B, int max_det, int nm,
+                       int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s) {
+  if (nm != 32) return -1;
+  if (in_h % mh || in_w % mw || in_w / mw != 4 || in_h / mh != 4 || in_w % 16) return -1;
+  const int tiles = ((mw + 15) / 16) * ((mh + 15) / 16);
+  hipLaunchKernelGGL(proto_masks_kernel<32>, dim3(tiles, max_det, B), dim3(256), 0, s, dets, counts, protos, max_det,
+                     mh, mw, in_h, in_w, masks);
+  return (int)hipGetLastError();
+}
+
+}  // namespace m355

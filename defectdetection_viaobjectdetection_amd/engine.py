@@ -1,0 +1,129 @@
+"""Python host wrapper of the libmi355yolo engine (PyTorch-ROCm tensors as device memory / streams).
+
+Stands where ``ultralytics.nn.tasks.SegmentationModel`` + ``SegmentationPredictor.postprocess`` stand
+upstream (call site /root/reference/BscanBased/yolo8_seg_predict.py:8): the
+arithmetic is in the HIP kernels behind the C-ABI, this file only owns buffers and argument plumbing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _capi
+from ._capi import ConvInfo, ModelDesc, check, lib
+from .spec import ConvSpec, conv_specs, fold_bn
+
+
+def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class SegEngine:
+    """One engine per device.  Not thread-safe (one handle, one caller)."""
+
+    def __init__(self, scale: str = "s", nc: int = 1, imgsz: Tuple[int, int] = (640, 640),
+                 max_batch: int = 32, device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("libmi355yolo needs a gfx950 GPU; there is no CPU fallback")
+        self.device = torch.device("cuda", device)
+        self.scale, self.nc, self.imgsz, self.max_batch = scale, nc, tuple(imgsz), max_batch
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            torch.cuda.init()
+            desc = ModelDesc(ord(scale), nc, imgsz[0], imgsz[1], max_batch)
+            check(lib.m355_create(C.byref(desc), C.byref(self._h)))
+        self.num_anchors = lib.m355_num_anchors(self._h)
+        self.pred_width = lib.m355_pred_width(self._h)
+        ph, pw = C.c_int(), C.c_int()
+        check(lib.m355_proto_hw(self._h, C.byref(ph), C.byref(pw)), self._h)
+        self.proto_hw = (ph.value, pw.value)
+        self.nm = 32
+        self.flops_per_image = lib.m355_flops_per_image(self._h)
+        self.workspace_bytes = lib.m355_workspace_bytes(self._h)
+        self.specs: List[ConvSpec] = conv_specs(scale, nc)
+        self._check_graph()
+
+    # ------------------------------------------------------------------ graph / weights
+    def conv_infos(self) -> List[ConvInfo]:
+        out = []
+        for i in range(lib.m355_num_convs(self._h)):
+            ci = ConvInfo()
+            check(lib.m355_get_conv_info(self._h, i, C.byref(ci)), self._h)
+            out.append(ci)
+        return out
+
+    def _check_graph(self) -> None:
+        infos = self.conv_infos()
+        if len(infos) != len(self.specs):
+            raise RuntimeError(f"engine reports {len(infos)} convs, host spec has {len(self.specs)}")
+        for ci, s in zip(infos, self.specs):
+            got = (ci.name.decode(), ci.cin, ci.cout, ci.k, ci.stride, bool(ci.has_bn), bool(ci.transposed))
+            want = (s.name, s.cin, s.cout, s.k, s.stride, s.has_bn, s.transposed)
+            if got != want:
+                raise RuntimeError(f"engine/host graph mismatch: {got} vs {want}")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Fold BN on the host (A4) and hand fp32 weights to the engine, which packs them to fp16."""
+        with torch.cuda.device(self.device):
+            for i, s in enumerate(self.specs):
+                w, b = fold_bn(sd, s)
+                if tuple(w.shape) != s.weight_shape or b.numel() != s.cout:
+                    raise ValueError(f"{s.name}: weight shape {tuple(w.shape)} != {s.weight_shape}")
+                check(lib.m355_set_conv_weights(self._h, i, _ptr(w), _ptr(b)), self._h)
+
+    # ------------------------------------------------------------------ forward / postprocess
+    def forward(self, images_u8_nhwc: torch.Tensor):
+        """images: uint8 (B,H,W,3) on this device.  Returns preds f32 (B,A,4+nc+32), protos f16 (B,h,w,32)."""
+        x = images_u8_nhwc
+        if x.dtype != torch.uint8 or x.dim() != 4 or x.shape[3] != 3 or tuple(x.shape[1:3]) != self.imgsz:
+            raise ValueError(f"expected uint8 (B,{self.imgsz[0]},{self.imgsz[1]},3), got {x.dtype} {tuple(x.shape)}")
+        if not x.is_cuda or not x.is_contiguous():
+            raise ValueError("input must be a contiguous CUDA tensor")
+        B = x.shape[0]
+        preds = torch.empty((B, self.num_anchors, self.pred_width), dtype=torch.float32, device=x.device)
+        protos = torch.empty((B, self.proto_hw[0], self.proto_hw[1], self.nm), dtype=torch.float16, device=x.device)
+        check(lib.m355_forward(self._h, _ptr(x), B, _ptr(preds), _ptr(protos), _stream()), self._h)
+        return preds, protos
+
+    def raw_head(self, batch: int) -> torch.Tensor:
+        """Copy of the raw head maps (B,A,64+nc+32) f32 of the last forward (A13 layout)."""
+        p, w = C.c_void_p(), C.c_int()
+        check(lib.m355_get_raw_head(self._h, C.byref(p), C.byref(w)), self._h)
+        out = torch.empty((batch, self.num_anchors, w.value), dtype=torch.float32, device=self.device)
+        check(lib.m355_copy_raw_head(self._h, batch, _ptr(out), _stream()), self._h)
+        return out
+
+    def postprocess(self, preds: torch.Tensor, protos: Optional[torch.Tensor], conf: float = 0.25,
+                    iou: float = 0.7, max_det: int = 300, masks: bool = True):
+        """Batched NMS + mask assembly.  Returns dets f32 (B,max_det,38), counts i32 (B),
+        masks u8 (B,max_det,H,W) or None.  Only rows < counts[b] are defined."""
+        B = preds.shape[0]
+        dets = torch.empty((B, max_det, 6 + self.nm), dtype=torch.float32, device=preds.device)
+        counts = torch.empty((B,), dtype=torch.int32, device=preds.device)
+        m = None
+        if masks:
+            m = torch.empty((B, max_det, self.imgsz[0], self.imgsz[1]), dtype=torch.uint8, device=preds.device)
+        check(lib.m355_postprocess(self._h, _ptr(preds), _ptr(protos), B, conf, iou, max_det, _ptr(dets),
+                                   _ptr(counts), _ptr(m), _stream()), self._h)
+        return dets, counts, m
+
+    def close(self) -> None:
+        if getattr(self, "_h", None) is not None and self._h.value:
+            lib.m355_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def version() -> str:
+    return _capi.version()

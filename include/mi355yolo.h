@@ -1,0 +1,139 @@
+/*
+ * mi355yolo.h -- C-ABI of libmi355yolo.so: the MI355X (gfx950) native YOLOv8-seg hot path.
+ *
+ * The reference (CSMaus/DefectDetection_viaObjectDetection) has no FFI of its own: its hot path is the
+ * Python call `YOLO(w).predict(src, save=True)` / `.train(...)` into the un-vendored `ultralytics`
+ * package (BscanBased/yolo8_seg_predict.py:5-9, BscanBased/yolo_seg_train.py:7-19).  This header is the
+ * boundary a maintainer binds instead (ctypes stub in INTEGRATION.md); each entry point names the
+ * upstream stage it replaces (SURVEY.md section 8a row ids A3..A12).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++ / torch types; no exceptions cross the boundary.
+ *   - return 0 on success, negative m355_status on error; text via m355_last_error().
+ *   - every device buffer is CALLER-OWNED (e.g. a PyTorch-ROCm tensor's data_ptr()); the library owns
+ *     only the weights + workspace inside the engine handle.
+ *   - every call is ASYNCHRONOUS on the caller's stream (`stream` is a hipStream_t passed as void*),
+ *     no hidden synchronisation -- except the entry points marked [sync], which exist for unit parity.
+ *   - one engine per device; an engine is not thread-safe; distinct engines are.
+ *   - there is NO CPU fallback: without a gfx950 device m355_create fails with M355_ERR_NO_DEVICE.
+ */
+#ifndef MI355YOLO_H_
+#define MI355YOLO_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct m355_engine m355_engine;
+
+typedef enum {
+  M355_OK = 0,
+  M355_ERR_INVALID = -1,    /* bad argument / shape */
+  M355_ERR_NO_DEVICE = -2,  /* no gfx950 device visible */
+  M355_ERR_HIP = -3,        /* HIP runtime error (text in last_error) */
+  M355_ERR_STATE = -4,      /* weights not loaded, batch too large, ... */
+  M355_ERR_NOMEM = -5
+} m355_status;
+
+/* Model description: replaces `YOLO("yolov8{n,s,m,l,x}-seg.yaml")` graph construction
+ * (yolo_seg_train.py:7).  nc = number of classes (data-seg.yaml:4-5 -> 1). */
+typedef struct {
+  int scale;      /* 'n','s','m','l','x' */
+  int nc;         /* classes */
+  int in_h, in_w; /* network input size, multiples of 32 (640x640 headline) */
+  int max_batch;  /* workspace is sized for this many images */
+} m355_model_desc;
+
+/* One convolution of the graph, in canonical order (the order weights are supplied in). */
+typedef struct {
+  char name[64];   /* ultralytics state-dict prefix, e.g. "model.2.m.0.cv1" (conv+bn) or
+                      "model.22.cv2.0.2" (plain conv2d with bias) or "model.22.proto.upsample" */
+  int cin, cout;   /* logical channels */
+  int k, stride;   /* kernel size (1,2,3), stride */
+  int has_bn;      /* 1: Conv2d(bias=False)+BN+SiLU (fold BN before m355_set_conv_weights) */
+  int transposed;  /* 1: ConvTranspose2d(k=2,s=2,bias) -- weight layout (cin,cout,2,2) */
+  int act;         /* 1: SiLU epilogue */
+} m355_conv_info;
+
+/* Version / build info string (static storage). */
+const char* m355_version(void);
+
+/* Last error text for this engine (or the last global error when e == NULL). */
+const char* m355_last_error(const m355_engine* e);
+
+/* Build the layer plan + allocate weights/workspace on the current HIP device.           [sync] */
+int m355_create(const m355_model_desc* desc, m355_engine** out);
+void m355_destroy(m355_engine* e);
+
+/* Graph introspection (lets the host map a state dict onto the engine). */
+int m355_num_convs(const m355_engine* e);
+int m355_get_conv_info(const m355_engine* e, int idx, m355_conv_info* out);
+int m355_num_anchors(const m355_engine* e);           /* 8400 at 640x640 */
+int m355_pred_width(const m355_engine* e);            /* 4 + nc + 32 */
+int m355_proto_hw(const m355_engine* e, int* h, int* w); /* 160x160 at 640 */
+size_t m355_workspace_bytes(const m355_engine* e);
+double m355_flops_per_image(const m355_engine* e);    /* 2 * conv MACs */
+
+/* Supply BN-folded fp32 weights of conv `idx` (host pointers, copied; caller keeps ownership):
+ * w is (cout,cin,k,k) [or (cin,cout,2,2) when transposed], bias is (cout).  Replaces upstream
+ * `fuse()` + `.to(device)`.                                                  [sync] */
+int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* bias);
+
+/* Inference forward: d_in is uint8 NHWC (B,in_h,in_w,3) letterboxed pixels in
+ * [0,255] (the /255 normalisation is folded into the stem conv).  Outputs:
+ *   d_preds  float32 (B, A, 4+nc+32): [cx,cy,w,h (pixels), class scores (sigmoid), 32 mask coefs]
+ *   d_protos float16 (B, H/4, W/4, 32) NHWC
+ * This is upstream's (B,4+nc+32,A) / (B,32,H/4,W/4) pair in anchor-major / NHWC order. */
+int m355_forward(m355_engine* e, const void* d_in_u8_nhwc, int batch, float* d_preds, void* d_protos,
+                 void* stream);
+
+/* Train-mode style raw head maps: float32 (B, A, 64+nc+32) = [box DFL logits(64),
+ * class logits(nc), mask coefs(32)] before decode.  Valid after m355_forward on the same stream. */
+int m355_get_raw_head(m355_engine* e, const float** d_raw, int* width);
+/* Asynchronous device-to-device copy of the first `batch` images of the raw head maps into d_out. */
+int m355_copy_raw_head(m355_engine* e, int batch, float* d_out, void* stream);
+
+/* Post-processing: batched NMS + mask assembly.
+ *   d_dets   float32 (B, max_det, 6+32)  rows [x1,y1,x2,y2,conf,cls,coefs] in letterboxed pixels,
+ *            sorted by confidence descending
+ *   d_counts int32 (B)
+ *   d_masks  uint8 (B, max_det, in_h, in_w) binary masks (may be NULL to skip mask assembly) */
+int m355_postprocess(m355_engine* e, const float* d_preds, const void* d_protos, int batch, float conf,
+                     float iou, int max_det, float* d_dets, int* d_counts, uint8_t* d_masks, void* stream);
+
+/* ---- per-op entry points for unit parity (all device pointers, asynchronous unless noted) ---- */
+
+/* NHWC fp16 convolution + bias (+SiLU) (+residual) via the implicit-GEMM MFMA kernel.
+ * h_w fp32 (cout,cin,k,k) and h_bias fp32 (cout) are HOST pointers, packed + uploaded here.  [sync] */
+int m355_conv2d_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, const float* h_w,
+                    const float* h_bias, int cout, int k, int stride, int act,
+                    const void* d_res_f16_nhwc, void* d_y_f16_nhwc, int out_f32, int force_tile,
+                    void* stream);
+/* ConvTranspose2d(k=2,s=2)+bias; h_w fp32 (cin,cout,2,2).                                   [sync] */
+int m355_convt2x2_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, const float* h_w,
+                      const float* h_bias, int cout, void* d_y_f16_nhwc, void* stream);
+/* Stem conv: uint8 NHWC (B,H,W,3) -> fp16 NHWC (B,H/2,W/2,cout), 3x3 s2 p1 + bias + SiLU;
+ * h_w fp32 (cout,3,3,3) is applied to pixel/255.                                            [sync] */
+int m355_stem_fwd(const void* d_in_u8, int B, int H, int W, const float* h_w, const float* h_bias, int cout,
+                  void* d_y_f16_nhwc, void* stream);
+/* SPPF pooling: x fp16 NHWC (B,H,W,C) -> y (B,H,W,3C) = [mp5(x), mp5(mp5(x)), mp5^3(x)]. */
+int m355_sppf_pool(const void* d_x, int B, int H, int W, int C, void* d_y, void* stream);
+/* Nearest 2x upsample, fp16 NHWC (B,H,W,C) -> (B,2H,2W,C). */
+int m355_upsample2x(const void* d_x, int B, int H, int W, int C, void* d_y, void* stream);
+/* Head decode: raw (B,A,64+nc+32) f32 -> preds (B,A,4+nc+32) f32 for an in_h x in_w input. */
+int m355_head_decode(const float* d_raw, int B, int in_h, int in_w, int nc, float* d_preds, void* stream);
+/* Batched NMS only. preds (B,A,4+nc+nm). */
+int m355_nms(const float* d_preds, int B, int A, int nc, int nm, float conf, float iou, int max_det,
+             float* d_dets, int* d_counts, void* stream);
+/* Mask assembly only: dets (B,max_det,6+32), counts (B), protos fp16 (B,mh,mw,32)
+ * -> masks uint8 (B,max_det,in_h,in_w). */
+int m355_proto_masks(const float* d_dets, const int* d_counts, const void* d_protos, int B, int max_det,
+                     int mh, int mw, int in_h, int in_w, uint8_t* d_masks, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355YOLO_H_ */
