@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s @640x640, batch 32, YOLOv8s-seg (BASELINE.json metric, configs[1]).
+
+A "step" = one pass of the hot path over one device-resident batch of 32 synthetic 640x640 B-scans:
+forward (75 convs + ConvT + pools + decode) + batched NMS + mask assembly, all on the HIP kernels behind
+the C-ABI.  Inputs are resident in HBM before the timed region.  One process per GPU; inference shards
+the image batch across ranks with NO data-path collective (weak scaling: 32 images per GPU per step);
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events recorded
+on the launch stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle, kind "port",
+timed on this node's host cores on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0   # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--scale", default="s")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-op HIP events")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import synthetic_bscans
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+
+    B = args.batch
+    sd = synthetic_state_dict(args.scale, 1, seed=0)
+    eng = SegEngine(args.scale, 1, (640, 640), max_batch=B, device=local_rank)
+    eng.load_state_dict(sd)
+    imgs = torch.from_numpy(synthetic_bscans(B, seed=1000 + rank)).cuda()
+    conf, iou, max_det = 0.25, 0.7, 300
+
+    # persistent output buffers (caller-owned), allocated once outside the timed region
+    import ctypes as C
+    from defectdetection_viaobjectdetection_amd._capi import check, lib
+    preds = torch.empty((B, eng.num_anchors, eng.pred_width), dtype=torch.float32, device="cuda")
+    protos = torch.empty((B, eng.proto_hw[0], eng.proto_hw[1], 32), dtype=torch.float16, device="cuda")
+    dets = torch.empty((B, max_det, 38), dtype=torch.float32, device="cuda")
+    counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    masks = torch.empty((B, max_det, 640, 640), dtype=torch.uint8, device="cuda")
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def step():
+        check(lib.m355_forward(eng._h, P(imgs), B, P(preds), P(protos), stream), eng._h)
+        check(lib.m355_postprocess(eng._h, P(preds), P(protos), B, conf, iou, max_det, P(dets), P(counts),
+                                   P(masks), stream), eng._h)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    profile = not args.no_profile
+    eng.set_profiling(profile)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_sum, cnt = eng.collect_op_times() if profile else ([], [])
+    eng.set_profiling(False)
+
+    total_images = world * B * args.steps
+    value = total_images / elapsed
+    out = {
+        "metric": "images/sec @640x640 b32 YOLOv8s-seg" if args.scale == "s" else f"images/sec @640x640 YOLOv8{args.scale}-seg",
+        "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
+        "config": {"workload": f"YOLOv8{args.scale}-seg inference (forward + NMS + masks), {B} synthetic 640x640 "
+                               f"B-scans per GPU per step, nc=1, seeded synthetic weights",
+                   "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
+                   "conf": conf, "iou": iou, "max_det": max_det,
+                   "mean_detections_per_image": round(float(counts.float().mean()), 2)},
+    }
+    if rank == 0:
+        gflop_img = eng.flops_per_image / 1e9
+        out["config"]["conv_gflop_per_image"] = round(gflop_img, 3)
+        out["config"]["whole_net_tflops"] = round(value / world * gflop_img / 1e3, 2)
+        if profile:
+            infos = eng.op_infos()
+            by_kernel = {}
+            for info, ms, c in zip(infos, ms_sum, cnt):
+                k = by_kernel.setdefault(info["kernel"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
+                k["ms"] += ms
+                k["launches"] += c
+                k["flops"] += info["flops"] * B * c
+                k["bytes"] += (info["bytes"] * B + info["weight_bytes"]) * c
+            dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+            d = by_kernel[dom]
+            fwd_ms = sum(ms_sum) / args.steps
+            if d["flops"] > 0:
+                achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                roof = {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None}
+            else:
+                achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+            roof["launches_per_step"] = d["launches"] // args.steps
+            roof["avg_launch_us"] = round(1e3 * d["ms"] / max(d["launches"], 1), 2)
+            roof["algorithmic_gflop_per_launch"] = round(d["flops"] / max(d["launches"], 1) / 1e9, 3)
+            roof["share_of_forward_ms"] = round(d["ms"] / max(sum(ms_sum), 1e-9), 3)
+            out["roofline"] = roof
+            out["kernels"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 4), "launches_per_step": v["launches"] // args.steps,
+                                  "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1) if v["ms"] > 0 else 0.0,
+                                  "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
+                              for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])}
+            out["forward_ms_per_step_events"] = round(fwd_ms, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.scale, sd)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def host_cores():
+    """CPU threads this process may really use: the cgroup quota if there is one, else the affinity mask,
+    capped at 16 (a one-GPU box's CPU share on this pool) so the baseline is not oversubscribed."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
+def cpu_baseline(scale, sd):
+    """The CPU oracle (a restatement of the Ultralytics CPU path; kind "port") on this node's host cores,
+    bounded sample: batches of 8 of the same synthetic workload, 1 warm-up + timed iterations for ~15 s."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import yolov8_seg_oracle as orc
+    from helpers import synthetic_bscans
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    model = orc.SegmentationModel(scale, 1)
+    model.load_state_dict(sd)
+    model.eval()
+    bs = 8
+    imgs = synthetic_bscans(bs, seed=1000)
+    x = torch.from_numpy(imgs.transpose(0, 3, 1, 2).copy()).float() / 255.0
+
+    def one():
+        with torch.no_grad():
+            preds, protos = model(x)
+        dets = orc.non_max_suppression(preds.numpy(), 1, 0.25, 0.7, 300)
+        for i, d in enumerate(dets):
+            orc.process_mask(protos[i], torch.from_numpy(d[:, 6:]), torch.from_numpy(d[:, :4]), (640, 640))
+
+    one()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        one()
+        n += 1
+        el = time.perf_counter() - t0
+        if el > 15.0 or n >= 40:
+            break
+    return {"value": round(n * bs / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} iterations of batch {bs} (640x640 synthetic B-scans) after 1 warm-up, PyTorch-CPU fp32 "
+                      f"forward + numpy NMS + mask assembly, {cores} threads"}
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,11 @@ class ConvInfo(C.Structure):
                 ("stride", C.c_int), ("has_bn", C.c_int), ("transposed", C.c_int), ("act", C.c_int)]
 
 
+class OpInfo(C.Structure):
+    _fields_ = [("kernel", C.c_char * 48), ("layer", C.c_char * 64), ("flops_per_image", C.c_double),
+                ("bytes_per_image", C.c_double), ("weight_bytes", C.c_double)]
+
+
 # symbol -> (restype, argtypes); every entry of include/mi355yolo.h
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
@@ -43,6 +48,10 @@ SIGNATURES = {
     "m355_flops_per_image": (C.c_double, [_P]),
     "m355_set_conv_weights": (C.c_int, [_P, C.c_int, _P, _P]),
     "m355_forward": (C.c_int, [_P, _P, C.c_int, _P, _P, _P]),
+    "m355_num_ops": (C.c_int, [_P]),
+    "m355_get_op_info": (C.c_int, [_P, C.c_int, C.POINTER(OpInfo)]),
+    "m355_set_profiling": (C.c_int, [_P, C.c_int]),
+    "m355_collect_op_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "m355_get_raw_head": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
     "m355_copy_raw_head": (C.c_int, [_P, C.c_int, _P, _P]),
     "m355_postprocess": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P, _P]),

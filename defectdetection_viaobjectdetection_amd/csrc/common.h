@@ -42,6 +42,8 @@ struct ConvArgs {
 enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3 };
 
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s);
+// tile heuristic: cout = (virtual) output channels, M = output pixels of the whole batch
+int conv_pick_tile(int cout, long M);
 // rows the packed weight buffer must be padded to for a given Cout (multiple of the channel tile)
 int conv_cout_pad(int cout);
 int conv_kpad(int cin, int ksize);

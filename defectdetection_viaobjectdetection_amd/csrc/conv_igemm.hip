@@ -303,18 +303,18 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
 int conv_cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 int conv_kpad(int cin, int ksize) { return (cin * ksize * ksize + BK - 1) / BK * BK; }
 
+int conv_pick_tile(int cout, long M) {
+  (void)M;
+  if (cout > 64) return TILE_128x128;
+  if (cout > 32) return TILE_64x128;
+  return TILE_32x256;
+}
+
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s) {
   if (a.ksize != 1 && a.ksize != 3) return -1;
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
   int tile = force_tile;
-  if (tile < 0) {
-    if (a.Cout > 64)
-      tile = TILE_128x128;
-    else if (a.Cout > 32)
-      tile = TILE_64x128;
-    else
-      tile = TILE_32x256;
-  }
+  if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
   switch (tile) {
     case TILE_128x128: return launch_variant<4, 4, 2, 2>(a, s);
     case TILE_64x128: return launch_variant<4, 2, 1, 4>(a, s);

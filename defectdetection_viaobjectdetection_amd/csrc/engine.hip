@@ -48,6 +48,13 @@ struct Op {
   int raw_off = 0;     // channel offset in raw buffer
   int level_off = 0;   // anchor offset of the level in the raw buffer
   int Hi = 0, Wi = 0;
+  // measurement metadata (per image)
+  char kernel[48] = {0};  // kernel family label, e.g. "conv_igemm<128x128,k3>"
+  char layer[64] = {0};   // first logical layer name
+  double flops = 0;       // algorithmic FLOPs per image (2*MACs; 0 for non-conv ops)
+  double bytes = 0;       // algorithmic activation bytes per image (in + out + residual)
+  double wbytes = 0;      // weight bytes (read once per launch)
+  int tile = -1;
 };
 
 // A physical conv = what one kernel launch computes.  Usually one logical conv; the three first-layer
@@ -82,6 +89,12 @@ struct m355_engine {
   size_t ws_bytes = 0;
   double macs = 0;           // conv MACs per image
   int feat_in = -1;
+  // profiling: HIP events around every op launch, recorded on the caller's stream
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;   // 2 events per op per recorded forward
+  size_t ev_used = 0;
+  std::vector<double> op_ms;         // accumulated per-op milliseconds
+  std::vector<long> op_cnt;
 
   int fail(int code, const std::string& m) {
     err = m;
@@ -383,6 +396,65 @@ int alloc_all(m355_engine* e) {
   return 0;
 }
 
+// Fill the measurement metadata of every op and fix the conv tile choice (algorithmic
+// FLOPs = 2*MACs; algorithmic bytes = every activation read once + written once, weights once).
+void annotate_ops(m355_engine* e) {
+  static const char* tile_names[] = {"128x128", "64x128", "32x256", "64x256"};
+  for (Op& op : e->ops) {
+    if (op.conv >= 0) snprintf(op.layer, sizeof(op.layer), "%s", e->convs[e->phys[op.conv].logical[0]].name);
+    switch (op.kind) {
+      case OP_STEM: {
+        const PhysConv& p = e->phys[op.conv];
+        const Tensor& to = e->tensors[op.out.t];
+        snprintf(op.kernel, sizeof(op.kernel), "stem_conv<k3s2,u8>");
+        op.flops = 2.0 * to.H * to.W * p.cout * 27;
+        op.bytes = (double)op.Hi * op.Wi * 3 + (double)to.H * to.W * p.cout * 2;
+        op.wbytes = 28.0 * p.cout * 4;
+        break;
+      }
+      case OP_CONV:
+      case OP_CONVT: {
+        const PhysConv& p = e->phys[op.conv];
+        const Tensor& ti = e->tensors[op.in.t];
+        int Ho, Wo, cout_v = p.cout, k = p.k;
+        if (op.kind == OP_CONVT) {
+          Ho = ti.H; Wo = ti.W; cout_v = 4 * p.cout; k = 1;
+          op.flops = 2.0 * Ho * Wo * p.cin * cout_v;
+        } else {
+          Ho = (ti.H + 2 * (p.k / 2) - p.k) / p.stride + 1;
+          Wo = (ti.W + 2 * (p.k / 2) - p.k) / p.stride + 1;
+          op.flops = 2.0 * Ho * Wo * p.cout * p.cin * p.k * p.k;
+        }
+        op.tile = conv_pick_tile(cout_v, e->desc.max_batch * Ho * Wo);
+        snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d>", tile_names[op.tile], k);
+        op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)Ho * Wo * cout_v * (op.out_ext == 1 ? 4 : 2) +
+                   (op.res.t >= 0 ? (double)Ho * Wo * cout_v * 2 : 0.0);
+        op.wbytes = (double)p.cout_pad * p.Kpad * 2;
+        break;
+      }
+      case OP_POOL: {
+        const Tensor& t = e->tensors[op.in.t];
+        snprintf(op.kernel, sizeof(op.kernel), "sppf_pool");
+        snprintf(op.layer, sizeof(op.layer), "model.9.m");
+        op.bytes = (double)t.H * t.W * op.in.c * 2 * 4;
+        break;
+      }
+      case OP_UP: {
+        const Tensor& t = e->tensors[op.in.t];
+        snprintf(op.kernel, sizeof(op.kernel), "upsample2x");
+        snprintf(op.layer, sizeof(op.layer), "upsample");
+        op.bytes = (double)t.H * t.W * op.in.c * 2 * 5;
+        break;
+      }
+      case OP_DECODE:
+        snprintf(op.kernel, sizeof(op.kernel), "head_decode");
+        snprintf(op.layer, sizeof(op.layer), "model.22.decode");
+        op.bytes = (double)e->A * ((64 + e->nc + e->nm) + (4 + e->nc + e->nm)) * 4;
+        break;
+    }
+  }
+}
+
 // Pack fp32 (cout,cin,k,k) -> fp16 rows [row0+co][ (kh*k+kw)*cin + ci ] of a [cout_pad][Kpad] matrix.
 void pack_conv_rows(const float* w, int cout, int cin, int k, int Kpad, int row0, std::vector<half_t>& dst) {
   for (int co = 0; co < cout; ++co)
@@ -426,6 +498,7 @@ int m355_create(const m355_model_desc* desc, m355_engine** out) {
   e->desc = *desc;
   int rc = build_graph(e);
   if (rc == 0) rc = alloc_all(e);
+  if (rc == 0) annotate_ops(e);
   if (rc != 0) {
     g_err = e->err;
     m355_destroy(e);
@@ -447,6 +520,7 @@ void m355_destroy(m355_engine* e) {
   if (e->raw) (void)hipFree(e->raw);
   if (e->zero) (void)hipFree(e->zero);
   if (e->nms_ws) (void)hipFree(e->nms_ws);
+  for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   delete e;
 }
 
@@ -512,8 +586,19 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
     if (!e->conv_loaded[i]) return e->fail(M355_ERR_STATE, std::string("weights not set for ") + e->convs[i].name);
   hipStream_t s = (hipStream_t)stream;
   const int rw = 64 + e->nc + e->nm;
-  for (const Op& op : e->ops) {
+  for (size_t oi = 0; oi < e->ops.size(); ++oi) {
+    const Op& op = e->ops[oi];
     int rc = 0;
+    if (e->profiling) {
+      if (e->ev_used + 2 > e->ev_pool.size()) {
+        for (int i = 0; i < 2; ++i) {
+          hipEvent_t ev;
+          HIP_TRY(e, hipEventCreate(&ev));
+          e->ev_pool.push_back(ev);
+        }
+      }
+      HIP_TRY(e, hipEventRecord(e->ev_pool[e->ev_used], s));
+    }
     switch (op.kind) {
       case OP_STEM: {
         const PhysConv& p = e->phys[op.conv];
@@ -560,7 +645,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           a.res = tr.p + op.res.off; a.r_bstride = (long)tr.H * tr.W * tr.C; a.ldr = tr.C;
         }
         a.M = B * a.Ho * a.Wo;
-        rc = launch_conv_igemm(a, TILE_AUTO, s);
+        rc = launch_conv_igemm(a, op.tile, s);
         break;
       }
       case OP_POOL: {
@@ -580,9 +665,53 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         rc = launch_head_decode(e->raw, B, e->desc.in_h, e->desc.in_w, e->nc, e->nm, d_preds, s);
         break;
     }
+    if (e->profiling) {
+      HIP_TRY(e, hipEventRecord(e->ev_pool[e->ev_used + 1], s));
+      e->ev_used += 2;
+    }
     if (rc != 0) return e->fail(M355_ERR_HIP, "kernel launch failed (op kind " + std::to_string((int)op.kind) +
                                                   ", code " + std::to_string(rc) + ")");
   }
+  return M355_OK;
+}
+
+int m355_num_ops(const m355_engine* e) { return e ? (int)e->ops.size() : M355_ERR_INVALID; }
+
+int m355_get_op_info(const m355_engine* e, int idx, m355_op_info* out) {
+  if (!e || !out || idx < 0 || idx >= (int)e->ops.size()) return M355_ERR_INVALID;
+  const Op& op = e->ops[idx];
+  memset(out, 0, sizeof(*out));
+  snprintf(out->kernel, sizeof(out->kernel), "%s", op.kernel);
+  snprintf(out->layer, sizeof(out->layer), "%s", op.layer);
+  out->flops_per_image = op.flops;
+  out->bytes_per_image = op.bytes;
+  out->weight_bytes = op.wbytes;
+  return M355_OK;
+}
+
+int m355_set_profiling(m355_engine* e, int enable) {
+  if (!e) return M355_ERR_INVALID;
+  e->profiling = enable != 0;
+  e->ev_used = 0;
+  e->op_ms.assign(e->ops.size(), 0.0);
+  e->op_cnt.assign(e->ops.size(), 0);
+  return M355_OK;
+}
+
+int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts) {
+  if (!e || !ms_sum || !counts) return M355_ERR_INVALID;
+  const size_t n = e->ops.size();
+  if (e->op_ms.size() != n) { e->op_ms.assign(n, 0.0); e->op_cnt.assign(n, 0); }
+  for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+    const size_t oi = (i / 2) % n;
+    HIP_TRY(e, hipEventSynchronize(e->ev_pool[i + 1]));
+    float ms = 0.f;
+    HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
+    e->op_ms[oi] += ms;
+    e->op_cnt[oi] += 1;
+  }
+  e->ev_used = 0;
+  for (size_t i = 0; i < n; ++i) { ms_sum[i] = e->op_ms[i]; counts[i] = e->op_cnt[i]; }
   return M355_OK;
 }
 

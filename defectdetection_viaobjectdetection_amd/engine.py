@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 
 from . import _capi
-from ._capi import ConvInfo, ModelDesc, check, lib
+from ._capi import ConvInfo, ModelDesc, OpInfo, check, lib
 from .spec import ConvSpec, conv_specs, fold_bn
 
 
@@ -112,6 +112,27 @@ class SegEngine:
         check(lib.m355_postprocess(self._h, _ptr(preds), _ptr(protos), B, conf, iou, max_det, _ptr(dets),
                                    _ptr(counts), _ptr(m), _stream()), self._h)
         return dets, counts, m
+
+    # ------------------------------------------------------------------ measurement hooks
+    def op_infos(self) -> List[dict]:
+        out = []
+        for i in range(lib.m355_num_ops(self._h)):
+            oi = OpInfo()
+            check(lib.m355_get_op_info(self._h, i, C.byref(oi)), self._h)
+            out.append(dict(kernel=oi.kernel.decode(), layer=oi.layer.decode(), flops=oi.flops_per_image,
+                            bytes=oi.bytes_per_image, weight_bytes=oi.weight_bytes))
+        return out
+
+    def set_profiling(self, enable: bool) -> None:
+        check(lib.m355_set_profiling(self._h, int(enable)), self._h)
+
+    def collect_op_times(self):
+        """Per-op (sum of milliseconds, launches) since profiling was enabled (HIP events on the launch stream)."""
+        n = lib.m355_num_ops(self._h)
+        ms = (C.c_double * n)()
+        cnt = (C.c_long * n)()
+        check(lib.m355_collect_op_times(self._h, ms, cnt), self._h)
+        return list(ms), list(cnt)
 
     def close(self) -> None:
         if getattr(self, "_h", None) is not None and self._h.value:

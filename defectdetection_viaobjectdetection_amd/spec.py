@@ -153,19 +153,34 @@ def init_state_dict(scale: str = "s", nc: int = 1, seed: int = 0) -> Dict[str, t
     return sd
 
 
-def synthetic_state_dict(scale: str = "s", nc: int = 1, seed: int = 0,
-                         cls_bias: float = -3.0) -> Dict[str, torch.Tensor]:
-    """Seeded *variance-preserving* weights for parity tests and the synthetic benchmark
-    (SURVEY 8d config 2): conv ~ U(+-g*sqrt(3/fan_in)) with g = 1.67 (SiLU keeps ~0.36 of the second
-    moment), non-trivial BN affine + running statistics so that folding is exercised, box-branch bias
-    1.0 and a class bias that lets on the order of 1 % of the anchors pass conf = 0.25, so NMS and mask
-    assembly do real work (default head-bias init would leave no detection at all)."""
+def _load_gains(scale: str) -> Dict[str, float]:
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", f"synth_gains_{scale}.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        return json.load(f)["gains"]
+
+
+def synthetic_state_dict(scale: str = "s", nc: int = 1, seed: int = 0, cls_bias: float = -3.5,
+                         gains: Dict[str, float] = None) -> Dict[str, torch.Tensor]:
+    """Seeded *scale-calibrated* weights for parity tests and the synthetic benchmark (SURVEY 8d
+    config 2).  conv ~ U(+-g*sqrt(3/fan_in)) where the per-layer gain g comes from
+    ``data/synth_gains_{scale}.json`` -- measured once so that every conv output has unit standard
+    deviation on synthetic B-scans (script: tests/golden/make_synth_gains.py; without the file g = 1.67,
+    the analytic SiLU compensation).  BN gets a non-trivial affine + running statistics so that folding is
+    exercised; the box-branch bias is 1.0 and the class bias lets on the order of 1 % of the anchors
+    pass conf = 0.25, so NMS and mask assembly do real work (the default head-bias init would leave no
+    detection at all)."""
+    if gains is None:
+        gains = _load_gains(scale)
     g = torch.Generator().manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
     for s in conv_specs(scale, nc):
         shape = s.weight_shape
         fan_in = (shape[0] if s.transposed else shape[1] * shape[2] * shape[3])
-        gain = 1.67 if s.has_bn else 1.0
+        gain = gains.get(s.name, 1.67 if s.has_bn else 1.0)
         bound = gain * math.sqrt(3.0 / fan_in)
         w = (torch.rand(shape, generator=g) * 2 - 1) * bound
         if s.has_bn:

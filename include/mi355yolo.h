@@ -90,6 +90,22 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
 int m355_forward(m355_engine* e, const void* d_in_u8_nhwc, int batch, float* d_preds, void* d_protos,
                  void* stream);
 
+/* ---- measurement hooks (bench.py's live roofline figure) ----
+ * One "op" = one kernel launch of the forward plan.  With profiling enabled m355_forward brackets every
+ * launch with hipEventRecord on the caller's stream; m355_collect_op_times synchronises those events
+ * and returns, per op, the accumulated milliseconds and number of launches since profiling was enabled. */
+typedef struct {
+  char kernel[48];        /* kernel family, e.g. "conv_igemm<128x128,k3>" */
+  char layer[64];         /* first state-dict prefix the launch computes */
+  double flops_per_image; /* algorithmic FLOPs (2*MACs), 0 for non-conv ops */
+  double bytes_per_image; /* algorithmic activation bytes: inputs read once + outputs written once */
+  double weight_bytes;    /* weight bytes, read once per launch */
+} m355_op_info;
+int m355_num_ops(const m355_engine* e);
+int m355_get_op_info(const m355_engine* e, int idx, m355_op_info* out);
+int m355_set_profiling(m355_engine* e, int enable);
+int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts);                  /* [sync] */
+
 /* Train-mode style raw head maps: float32 (B, A, 64+nc+32) = [box DFL logits(64),
  * class logits(nc), mask coefs(32)] before decode.  Valid after m355_forward on the same stream. */
 int m355_get_raw_head(m355_engine* e, const float** d_raw, int* width);
