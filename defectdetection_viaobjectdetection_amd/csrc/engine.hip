@@ -691,10 +691,7 @@ int m355_get_op_info(const m355_engine* e, int idx, m355_op_info* out) {
 
 int m355_set_profiling(m355_engine* e, int enable) {
   if (!e) return M355_ERR_INVALID;
-  e->profiling = enable != 0;
-  e->ev_used = 0;
-  e->op_ms.assign(e->ops.size(), 0.0);
-  e->op_cnt.assign(e->ops.size(), 0);
+  e->profiling = enable != 0;  // toggles recording only; m355_collect_op_times drains and resets
   return M355_OK;
 }
 
@@ -712,6 +709,8 @@ int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts) {
   }
   e->ev_used = 0;
   for (size_t i = 0; i < n; ++i) { ms_sum[i] = e->op_ms[i]; counts[i] = e->op_cnt[i]; }
+  e->op_ms.assign(n, 0.0);
+  e->op_cnt.assign(n, 0);
   return M355_OK;
 }
 

@@ -153,79 +153,112 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, in
 //   logits(y,x) = sum_c coef[c] * proto[y][x][c]      on the tile + 1-pixel halo (18x18), in LDS
 //   zero outside the box scaled to the prototype grid (x1 <= col < x2, y1 <= row < y2)
 //   bilinear upsample x(in/mh) with align_corners=False  -> 64x64 output pixels, mask = value > 0
-// One 256-thread block; each thread emits 16 consecutive output pixels (one 16-byte store).
+// Persistent 256-thread blocks walk the work list (detection, tile) built from the device-side counts
+// (no host sync, no empty blocks); each thread emits 16 consecutive output pixels per 16-byte store.
+// Tiles that do not touch the (halo-extended) box are zero-filled without reading the prototypes.
 // NM prototypes (32) * fp16 = one 64-byte NHWC pixel.
 // ---------------------------------------------------------------------------------------------
 template <int NM>
 __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, const int* counts, const half_t* protos,
-                                                          int max_det, int mh, int mw, int in_h, int in_w,
+                                                          int B, int max_det, int mh, int mw, int in_h, int in_w,
                                                           uint8_t* masks) {
-  const int b = blockIdx.z, k = blockIdx.y;
-  if (k >= counts[b]) return;
-  const int tiles_x = (mw + 15) / 16;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   __shared__ float lg[18][19];
   __shared__ float coef[NM];
-  const float* d = dets + ((long)b * max_det + k) * (6 + NM);
-  if (threadIdx.x < NM) coef[threadIdx.x] = d[6 + threadIdx.x];
-  const float wr = (float)mw / (float)in_w, hr = (float)mh / (float)in_h;
-  const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
-  __syncthreads();
-  const half_t* pb = protos + (long)b * mh * mw * NM;
-  for (int i = threadIdx.x; i < 18 * 18; i += 256) {
-    const int ly = i / 18, lx = i - ly * 18;
-    const int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
-    float v = 0.f;
-    if (y >= 0 && y < mh && x >= 0 && x < mw) {
-      const float xf = (float)x, yf = (float)y;
-      if (xf >= bx1 && xf < bx2 && yf >= by1 && yf < by2) {
-        const half8* pp = (const half8*)(pb + ((long)y * mw + x) * NM);
-        float s = 0.f;
-#pragma unroll
-        for (int c8 = 0; c8 < NM / 8; ++c8) {
-          const half8 h = pp[c8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) s += coef[c8 * 8 + j] * (float)h[j];
-        }
-        v = s;
-      }
-    }
-    lg[ly][lx] = v;
+  __shared__ int prefix[1025];  // prefix[b] = number of detections in images < b  (B <= 1024)
+  for (int i = threadIdx.x; i <= B; i += 256) {
+    int acc = 0;
+    for (int j = 0; j < i; ++j) acc += min(counts[j], max_det);
+    prefix[i] = acc;
   }
   __syncthreads();
+  const int tiles_x = (mw + 15) / 16, tiles_y = (mh + 15) / 16;
+  const int tiles = tiles_x * tiles_y;
+  const long total = (long)prefix[B] * tiles;
+  const float wr = (float)mw / (float)in_w, hr = (float)mh / (float)in_h;
   const int up_y = in_h / mh, up_x = in_w / mw;  // 4
   const float sy = (float)mh / (float)in_h, sx = (float)mw / (float)in_w;
   const int out_w = 16 * up_x, out_h = 16 * up_y;  // 64 x 64 per tile
   const int segs = out_w / 16;
-  for (int i = threadIdx.x; i < out_h * segs; i += 256) {
-    const int oy = i / segs, seg = i - oy * segs;
-    const int Y = ty * out_h + oy;
-    if (Y >= in_h) continue;
-    float fy = sy * ((float)Y + 0.5f) - 0.5f;
-    if (fy < 0.f) fy = 0.f;
-    const int y0 = (int)fy;
-    const int y1 = y0 < mh - 1 ? y0 + 1 : y0;
-    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-    const int r0 = y0 - (ty * 16 - 1), r1 = y1 - (ty * 16 - 1);
-    uint8_t o[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const int X = tx * out_w + seg * 16 + j;
-      float fx = sx * ((float)X + 0.5f) - 0.5f;
-      if (fx < 0.f) fx = 0.f;
-      const int x0 = (int)fx;
-      const int x1 = x0 < mw - 1 ? x0 + 1 : x0;
-      const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-      const int c0 = x0 - (tx * 16 - 1), c1 = x1 - (tx * 16 - 1);
-      const float v = ly0 * (lx0 * lg[r0][c0] + lx1 * lg[r0][c1]) + ly1 * (lx0 * lg[r1][c0] + lx1 * lg[r1][c1]);
-      o[j] = v > 0.f ? 1 : 0;
+  for (long item = blockIdx.x; item < total; item += gridDim.x) {
+    const int di = (int)(item / tiles), tile = (int)(item - (long)di * tiles);
+    int b = 0;
+    while (prefix[b + 1] <= di) ++b;  // uniform per block
+    const int k = di - prefix[b];
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const float* d = dets + ((long)b * max_det + k) * (6 + NM);
+    const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
+    // does the tile's 18x18 halo window contain any in-box prototype pixel?
+    const float wx0 = (float)(tx * 16 - 1), wx1 = (float)(tx * 16 + 16), wy0 = (float)(ty * 16 - 1),
+                wy1 = (float)(ty * 16 + 16);
+    const bool touches = !(wx1 < bx1 || wx0 >= bx2 || wy1 < by1 || wy0 >= by2);
+    uint8_t* mbase = masks + ((long)b * max_det + k) * in_h * in_w;
+    if (!touches) {
+      const uint4 z = make_uint4(0, 0, 0, 0);
+      for (int i = threadIdx.x; i < out_h * segs; i += 256) {
+        const int oy = i / segs, seg = i - oy * segs;
+        const int Y = ty * out_h + oy, X0 = tx * out_w + seg * 16;
+        if (Y >= in_h) continue;
+        uint8_t* mp = mbase + (long)Y * in_w + X0;
+        if (X0 + 16 <= in_w) *(uint4*)mp = z;
+        else for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = 0;
+      }
+      continue;
     }
-    const int X0 = tx * out_w + seg * 16;
-    uint8_t* mp = masks + (((long)b * max_det + k) * in_h + Y) * in_w + X0;
-    if (X0 + 16 <= in_w) {
-      *(uint4*)mp = *(const uint4*)o;
-    } else {
-      for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = o[j];
+    __syncthreads();  // previous item's readers of lg/coef are done
+    if (threadIdx.x < NM) coef[threadIdx.x] = d[6 + threadIdx.x];
+    __syncthreads();
+    const half_t* pb = protos + (long)b * mh * mw * NM;
+    for (int i = threadIdx.x; i < 18 * 18; i += 256) {
+      const int ly = i / 18, lx = i - ly * 18;
+      const int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
+      float v = 0.f;
+      if (y >= 0 && y < mh && x >= 0 && x < mw) {
+        const float xf = (float)x, yf = (float)y;
+        if (xf >= bx1 && xf < bx2 && yf >= by1 && yf < by2) {
+          const half8* pp = (const half8*)(pb + ((long)y * mw + x) * NM);
+          float s = 0.f;
+#pragma unroll
+          for (int c8 = 0; c8 < NM / 8; ++c8) {
+            const half8 h = pp[c8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += coef[c8 * 8 + j] * (float)h[j];
+          }
+          v = s;
+        }
+      }
+      lg[ly][lx] = v;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < out_h * segs; i += 256) {
+      const int oy = i / segs, seg = i - oy * segs;
+      const int Y = ty * out_h + oy;
+      if (Y >= in_h) continue;
+      float fy = sy * ((float)Y + 0.5f) - 0.5f;
+      if (fy < 0.f) fy = 0.f;
+      const int y0 = (int)fy;
+      const int y1 = y0 < mh - 1 ? y0 + 1 : y0;
+      const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+      const int r0 = y0 - (ty * 16 - 1), r1 = y1 - (ty * 16 - 1);
+      uint8_t o[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int X = tx * out_w + seg * 16 + j;
+        float fx = sx * ((float)X + 0.5f) - 0.5f;
+        if (fx < 0.f) fx = 0.f;
+        const int x0 = (int)fx;
+        const int x1 = x0 < mw - 1 ? x0 + 1 : x0;
+        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const int c0 = x0 - (tx * 16 - 1), c1 = x1 - (tx * 16 - 1);
+        const float v = ly0 * (lx0 * lg[r0][c0] + lx1 * lg[r0][c1]) + ly1 * (lx0 * lg[r1][c0] + lx1 * lg[r1][c1]);
+        o[j] = v > 0.f ? 1 : 0;
+      }
+      const int X0 = tx * out_w + seg * 16;
+      uint8_t* mp = mbase + (long)Y * in_w + X0;
+      if (X0 + 16 <= in_w) {
+        *(uint4*)mp = *(const uint4*)o;
+      } else {
+        for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = o[j];
+      }
     }
   }
 }
@@ -263,9 +296,9 @@ int launch_proto_masks(const float* dets, const int* counts, const half_t* proto
                        int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s) {
   if (nm != 32) return -1;
   if (in_h % mh || in_w % mw || in_w / mw != 4 || in_h / mh != 4 || in_w % 16) return -1;
-  const int tiles = ((mw + 15) / 16) * ((mh + 15) / 16);
-  hipLaunchKernelGGL(proto_masks_kernel<32>, dim3(tiles, max_det, B), dim3(256), 0, s, dets, counts, protos, max_det,
-                     mh, mw, in_h, in_w, masks);
+  if (B > 1024) return -1;
+  hipLaunchKernelGGL(proto_masks_kernel<32>, dim3(256 * 8), dim3(256), 0, s, dets, counts, protos, B, max_det, mh, mw,
+                     in_h, in_w, masks);
   return (int)hipGetLastError();
 }
 
