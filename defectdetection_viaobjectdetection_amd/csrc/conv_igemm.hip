@@ -12,11 +12,15 @@
 // v_mfma_f32_16x16x32_f16: lane l holds A[row l&15][k 8(l>>4)..+7], B[k 8(l>>4)..+7][col l&15],
 // D[row 4(l>>4)+j][col l&15].
 //
-// Data path: both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, one 16-byte chunk per
-// lane, per-lane SOURCE address = the im2col gather; padded taps read a zero page), two LDS stages, one
-// barrier per 64-deep K step; LDS rows are 128 B (64 halves) with the 16-byte chunk index XOR-swizzled
-// by (row & 7) -- applied on the source side (which chunk a lane fetches) and on the ds_read side, so
-// the LDS-DMA image stays lane-linear.  ds_read_b128 of a 16-row x 4-chunk fragment is conflict-free.
+// Structure: PERSISTENT workgroups (CUs x resident blocks) walk the (pixel tile, channel tile) list;
+// the loader is an independent cursor that runs two 64-deep K stages ahead of the MFMAs and crosses
+// tile boundaries, so the LDS-DMA pipeline never drains and a tile's epilogue overlaps the next tile's
+// first loads.  Both operands go HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4, one 16-byte chunk
+// per lane, per-lane SOURCE address = the im2col gather; padded taps read a zero page); two LDS stages;
+// one barrier per K step placed mid-step; fragment registers double-buffered so no MFMA waits on a
+// just-issued ds_read.  LDS rows are 128 B (64 halves) with the 16-byte chunk index XOR-swizzled by
+// (row & 7) -- applied on the source side (which chunk a lane fetches) and on the ds_read side, so the
+// LDS-DMA image stays lane-linear; ds_read_b128 of a 16-row x 4-chunk fragment is conflict-free.
 //
 // Epilogue: + bias, SiLU, + residual, fp16 pack, 16-byte stores of 8 consecutive channels at a channel
 // offset of a wider NHWC buffer (zero-copy concat); weight rows are permuted by the loader so that
@@ -39,9 +43,17 @@ __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// q = n / d, r = n % d for 0 <= n < 2^24 via a float reciprocal estimate + exact integer correction.
+__device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, int& r) {
+  q = (int)((float)n * inv_d);
+  r = n - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
+
 // MT/NT: 16x16 MFMA tiles per wave along channels / pixels.  WCH/WPX: waves along channels / pixels.
 template <int MT, int NT, int WCH, int WPX, int KS>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(WCH * WPX == 4, "4 waves");
   constexpr int BCH = WCH * MT * 16;  // channel tile
   constexpr int BPX = WPX * NT * 16;  // pixel tile
@@ -56,91 +68,104 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-  // ---- XCD-aware block -> tile map: blocks b, b+8, ... share an XCD (and its L2); give each XCD a
-  // contiguous run of logical tiles, channel tiles fastest, so the tiles that gather the same pixels
-  // (and their halo neighbours) hit the same L2.
+  // ---- tile list.  Blocks b, b+8, ... share an XCD (and its L2): logical block id lb groups them so
+  // that at any time the blocks of one XCD work on a contiguous run of tiles (channel tiles fastest):
+  // the tiles that gather the same pixels and their halo neighbours hit the same L2.
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;
+  const int tiles_px = (a.M + BPX - 1) / BPX;
+  const int total = tiles_ch * tiles_px;
   const int nwg = gridDim.x;
-  int logical;
+  int lb;
   {
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int tile_ch = logical % tiles_ch;
-  const int tile_px = logical / tiles_ch;
-  const int ch_base = tile_ch * BCH;
-  const int px_base = tile_px * BPX;
+  const int nk = a.Kpad / BK;
+  const int my_tiles = lb < total ? (total - lb + nwg - 1) / nwg : 0;
+  if (my_tiles == 0) return;
+  const int total_stages = my_tiles * nk;
 
-  // ---- loader state.  Each lane owns LDS slot (row = 8*i' + lane/8, slot = lane%8) of every
-  // 8-row group it loads; the source chunk for that slot is slot ^ (row & 7) = (lane&7) ^ (lane>>3).
+  // ---- loader.  Each lane owns LDS slot (row = 8*i' + lane/8, slot = lane%8) of every 8-row group it
+  // loads; the source chunk for that slot is slot ^ (row & 7) = (lane&7) ^ (lane>>3).
   const int lrow = lane >> 3;
   const int cc = (lane & 7) ^ lrow;  // this lane's K-chunk column (8 halves) within a K step
   const int HoWo = a.Ho * a.Wo;
-
-  long rowoff[A_IT];      // element offset of (b, hi0, wi0, 0) for each of this lane's pixel rows
-  unsigned rowmask[A_IT]; // bit t: tap t is inside the image (and the row is < M)
-#pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const int prow = wave * (BPX / 4) + i * 8 + lrow;
-    const int m = px_base + prow;
-    const bool mv = m < a.M;
-    const int mm = mv ? m : 0;
-    const int b = mm / HoWo;
-    const int pix = mm - b * HoWo;
-    const int ho = pix / a.Wo;
-    const int wo = pix - ho * a.Wo;
-    const int hi0 = ho * a.stride - a.pad;
-    const int wi0 = wo * a.stride - a.pad;
-    rowoff[i] = (long)b * a.x_bstride + ((long)hi0 * a.Wi + wi0) * a.ldx;
-    unsigned mk = 0;
-    if (mv) {
-#pragma unroll
-      for (int t = 0; t < KS * KS; ++t) {
-        const int kh = t / KS, kw = t % KS;
-        if ((unsigned)(hi0 + kh) < (unsigned)a.Hi && (unsigned)(wi0 + kw) < (unsigned)a.Wi) mk |= 1u << t;
-      }
-    }
-    rowmask[i] = mk;
-  }
-  // weights: LDS row R (tile-local) holds the weight row of the channel the MFMA row maps to, so
-  // that lane group g ends up owning 8 consecutive channels (see epilogue).  The permutation is applied
-  // on the SOURCE side; LDS rows stay in plain MFMA-tile order (conflict-free ds_read_b128).
-  const half_t* wsrc[W_IT];
-#pragma unroll
-  for (int i = 0; i < W_IT; ++i) {
-    const int R = wave * (BCH / 4) + i * 8 + lrow;
-    const int blk = R / (MT * 16), Rl = R % (MT * 16);
-    const int mt = Rl >> 4, r = Rl & 15;
-    int chl;
-    if (MT >= 2)
-      chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
-    else
-      chl = r;
-    wsrc[i] = a.w + (long)(ch_base + blk * MT * 16 + chl) * a.Kpad + cc * 8;
-  }
+  const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
   const float inv_cin = 1.0f / (float)a.Cin;
+  const float inv_tch = 1.0f / (float)tiles_ch;
 
-  auto stage = [&](int t, int buf) {
-    char* sb = smem + buf * STAGE;
-    // weights: rows [wave*BCH/4 + i*8, +8)
+  long rowoff[A_IT];        // element offset of (b, hi0, wi0, 0) for each of this lane's pixel rows
+  unsigned rowmask[A_IT];   // bit t: tap t is inside the image (and the row is < M)
+  const half_t* wsrc[W_IT]; // this lane's weight rows (+ chunk column)
+  int ld_tile = lb;         // loader cursor: tile, K step within the tile, global stage count
+  int ld_t = 0, ld_g = 0;
+
+  auto loader_setup = [&](int tile) {
+    int tile_px, tile_ch;
+    fast_divmod(tile, tiles_ch, inv_tch, tile_px, tile_ch);
+    const int px_base = tile_px * BPX, ch_base = tile_ch * BCH;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      const int prow = wave * (BPX / 4) + i * 8 + lrow;
+      const int m = px_base + prow;
+      const bool mv = m < a.M;
+      const int mm = mv ? m : 0;
+      int b, pix, ho, wo;
+      fast_divmod(mm, HoWo, inv_howo, b, pix);
+      fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+      const int hi0 = ho * a.stride - a.pad;
+      const int wi0 = wo * a.stride - a.pad;
+      rowoff[i] = (long)b * a.x_bstride + ((long)hi0 * a.Wi + wi0) * a.ldx;
+      unsigned mk = 0;
+      if (KS == 1) {
+        mk = mv ? 1u : 0u;
+      } else {
+        // bit kh*3+kw: tap inside the image (straight-line: a nested tap loop defeats full unrolling and
+        // sends rowoff[]/rowmask[] to scratch)
+        const unsigned rv = ((unsigned)hi0 < (unsigned)a.Hi ? 1u : 0u) | ((unsigned)(hi0 + 1) < (unsigned)a.Hi ? 2u : 0u) |
+                            ((unsigned)(hi0 + 2) < (unsigned)a.Hi ? 4u : 0u);
+        const unsigned cv = ((unsigned)wi0 < (unsigned)a.Wi ? 1u : 0u) | ((unsigned)(wi0 + 1) < (unsigned)a.Wi ? 2u : 0u) |
+                            ((unsigned)(wi0 + 2) < (unsigned)a.Wi ? 4u : 0u);
+        mk = ((rv & 1u) ? cv : 0u) | ((rv & 2u) ? (cv << 3) : 0u) | ((rv & 4u) ? (cv << 6) : 0u);
+        if (!mv) mk = 0;
+      }
+      rowmask[i] = mk;
+    }
+    // weights: LDS row R (tile-local) holds the weight row of the channel the MFMA row maps to, so that
+    // lane group g ends up owning 8 consecutive channels (see epilogue).  The permutation is applied on
+    // the SOURCE side; LDS rows stay in plain MFMA-tile order (conflict-free ds_read_b128).
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
-      glds16(wsrc[i] + t * BK, sb + (wave * (BCH / 4) + i * 8) * ROWB);
+      const int R = wave * (BCH / 4) + i * 8 + lrow;
+      const int blk = R / (MT * 16), Rl = R % (MT * 16);
+      const int mt = Rl >> 4, r = Rl & 15;
+      int chl;
+      if (MT >= 2)
+        chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
+      else
+        chl = r;
+      wsrc[i] = a.w + (long)(ch_base + blk * MT * 16 + chl) * a.Kpad + cc * 8;
+    }
+  };
+
+  // issue the LDS-DMA of the stage under the loader cursor into buffer (ld_g & 1), advance the cursor
+  auto stage_next = [&]() {
+    const int t = ld_t;
+    char* sb = smem + (ld_g & 1) * STAGE;
+    const bool skip_w = (a.dbg & 2) && ld_g > 1, skip_a = (a.dbg & 1) && ld_g > 1;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      if (!skip_w) glds16(wsrc[i] + t * BK, sb + (wave * (BCH / 4) + i * 8) * ROWB);
     }
     // activations: tap / cin of this lane's chunk at K step t
     const int kq = t * BK + cc * 8;
-    int tap, cin;
+    int tap, cin, tapoff;
     if (KS == 1) {
       tap = kq >= a.Cin ? 31 : 0;
-      cin = kq;
+      tapoff = kq;
     } else {
       tap = (int)(((float)kq + 0.5f) * inv_cin);
       cin = kq - tap * a.Cin;
-    }
-    int tapoff;
-    if (KS == 1) {
-      tapoff = cin;
-    } else {
       const int kh = (tap * 11) >> 5;  // tap/3 for tap < 12
       const int kw = tap - kh * 3;
       tapoff = (kh * a.Wi + kw) * a.ldx + cin;
@@ -150,7 +175,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     for (int i = 0; i < A_IT; ++i) {
       const bool ok = (rowmask[i] >> tap) & 1u;
       const half_t* src = ok ? (a.x + rowoff[i] + tapoff) : a.zero;
-      glds16(src, ab + (wave * (BPX / 4) + i * 8) * ROWB);
+      if (!skip_a) glds16(src, ab + (wave * (BPX / 4) + i * 8) * ROWB);
+    }
+    ++ld_g;
+    if (++ld_t == nk) {
+      ld_t = 0;
+      ld_tile += nwg;
+      if (ld_tile < total) loader_setup(ld_tile);
     }
   };
 
@@ -171,106 +202,145 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
 
   float4v acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+  half8 af0[MT], bf0[NT], af1[MT], bf1[NT];
 
-  const int nk = a.Kpad / BK;
-  stage(0, 0);
-  for (int t = 0; t < nk; ++t) {
+  // ---- pipeline prologue: two stages in flight, fragments ks=0 of stage 0 in registers
+  loader_setup(ld_tile);
+  stage_next();
+  if (total_stages > 1) {
+    stage_next();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(W_IT + A_IT) : "memory");  // stage 0 landed, stage 1 in flight
+  } else {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (t + 1 < nk) stage(t + 1, (t + 1) & 1);
-    const char* sb = smem + (t & 1) * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      half8 af[MT], bf[NT];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[mt] = *(const half8*)(sb + (aoff[mt] ^ (ks << 6)));
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) bf[nt] = *(const half8*)(sb + (boff[nt] ^ (ks << 6)));
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-    }
   }
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(smem + aoff[mt]);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bf0[nt] = *(const half8*)(smem + boff[nt]);
 
-  // ---- epilogue
+  // One 64-deep K step of global stage gs (buffer gs&1), software pipelined, barrier MID-step:
+  //   top : issue ds_reads ks=1(gs)   ->  16 MFMA ks=0(gs)          (read latency hidden)
+  //   mid : vmcnt(0)+lgkmcnt(0)+barrier => stage gs+1 has landed for every wave and every wave is
+  //         done reading stage gs -> issue ds_reads ks=0(gs+1), LDS-DMA for stage gs+2 into buffer
+  //         gs&1 -> 16 MFMA ks=1(gs)
+  int gs = 0;
+  auto kstep = [&]() {
+    const char* sb = smem + (gs & 1) * STAGE;
+    const char* sn = smem + ((gs + 1) & 1) * STAGE;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af1[mt] = *(const half8*)(sb + (aoff[mt] ^ 64));
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf1[nt] = *(const half8*)(sb + (boff[nt] ^ 64));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0[mt], bf0[nt], acc[mt][nt], 0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!(a.dbg & 8)) __builtin_amdgcn_s_barrier();
+    // ks=0 fragments of the next stage (after the very last stage this reads stale bytes, never used)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(sn + aoff[mt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf0[nt] = *(const half8*)(sn + boff[nt]);
+    if (ld_g < total_stages) stage_next();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[mt], bf1[nt], acc[mt][nt], 0, 0, 0);
+    ++gs;
+  };
+
   constexpr int GROUPS = (MT >= 2) ? MT / 2 : 1;  // 8-channel (MT>=2) or 4-channel (MT==1) groups per lane
   constexpr int GW = (MT >= 2) ? 8 : 4;
+
+  for (int tile = lb; tile < total; tile += nwg) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int m = px_base + wpx * NT * 16 + nt * 16 + l15;
-    if (m >= a.M) continue;
-    const int b = m / HoWo;
-    const int pix = m - b * HoWo;
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int s = 0; s < GROUPS; ++s) {
-      const int ch0 = ch_base + wch * MT * 16 + ((MT >= 2) ? (s * 32 + g * 8) : (g * 4));
-      if (ch0 >= a.Cout) continue;
-      float v[GW];
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nk; ++t) kstep();
+
+    // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
+    int tile_px, tile_ch;
+    fast_divmod(tile, tiles_ch, inv_tch, tile_px, tile_ch);
+    const int px_base = tile_px * BPX, ch_base = tile_ch * BCH;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (MT >= 2) {
-          v[j] = acc[2 * s][nt][j];
-          v[4 + j] = acc[2 * s + 1][nt][j];
-        } else {
-          v[j] = acc[0][nt][j];
+    for (int nt = 0; nt < NT; ++nt) {
+      const int m = px_base + wpx * NT * 16 + nt * 16 + l15;
+      if (m >= a.M) continue;
+      int b, pix;
+      fast_divmod(m, HoWo, inv_howo, b, pix);
+#pragma unroll
+      for (int s = 0; s < GROUPS; ++s) {
+        const int ch0 = ch_base + wch * MT * 16 + ((MT >= 2) ? (s * 32 + g * 8) : (g * 4));
+        if (ch0 >= a.Cout) continue;
+        float v[GW];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (MT >= 2) {
+            v[j] = acc[2 * s][nt][j];
+            v[4 + j] = acc[2 * s + 1][nt][j];
+          } else {
+            v[j] = acc[0][nt][j];
+          }
         }
-      }
-      long yoff;
-      int cidx = ch0;  // bias / output channel index
-      if (a.convt_co > 0) {
-        const int q = ch0 / a.convt_co;
-        cidx = ch0 - q * a.convt_co;
-        const int ho = pix / a.Wo, wo = pix - ho * a.Wo;
-        yoff = (long)b * a.y_bstride + ((long)(2 * ho + (q >> 1)) * (2 * a.Wo) + 2 * wo + (q & 1)) * a.ldy + cidx;
-      } else {
-        yoff = (long)b * a.y_bstride + (long)pix * a.ldy + ch0;
-      }
-#pragma unroll
-      for (int j = 0; j < GW; ++j) v[j] += a.bias[cidx + j];
-      if (a.act) {
-#pragma unroll
-        for (int j = 0; j < GW; ++j) v[j] = silu_f(v[j]);
-      }
-      if (a.res) {
-        const half_t* rp = a.res + (long)b * a.r_bstride + (long)pix * a.ldr + ch0;
-        if (GW == 8) {
-          const half8 rv = *(const half8*)rp;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+        long yoff;
+        int cidx = ch0;  // bias / output channel index
+        if (a.convt_co > 0) {
+          const int q = ch0 / a.convt_co;
+          cidx = ch0 - q * a.convt_co;
+          const int ho = pix / a.Wo, wo = pix - ho * a.Wo;
+          yoff = (long)b * a.y_bstride + ((long)(2 * ho + (q >> 1)) * (2 * a.Wo) + 2 * wo + (q & 1)) * a.ldy + cidx;
         } else {
-          const half4 rv = *(const half4*)rp;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+          yoff = (long)b * a.y_bstride + (long)pix * a.ldy + ch0;
         }
-      }
-      if (a.out_f32) {
-        float* yp = (float*)a.y + yoff;
 #pragma unroll
-        for (int j = 0; j < GW; ++j)
-          if (cidx + j < ((a.convt_co > 0) ? a.convt_co : a.Cout)) yp[j] = v[j];
-      } else {
-        half_t* yp = (half_t*)a.y + yoff;
-        if (GW == 8) {
-          half8 o;
+        for (int j = 0; j < GW; ++j) v[j] += a.bias[cidx + j];
+        if (a.act && !(a.dbg & 32)) {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-          *(half8*)yp = o;
+          for (int j = 0; j < GW; ++j) v[j] = silu_f(v[j]);
+        }
+        if (a.res) {
+          const half_t* rp = a.res + (long)b * a.r_bstride + (long)pix * a.ldr + ch0;
+          if (GW == 8) {
+            const half8 rv = *(const half8*)rp;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+          } else {
+            const half4 rv = *(const half4*)rp;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+          }
+        }
+        if (a.out_f32) {
+          float* yp = (float*)a.y + yoff;
+#pragma unroll
+          for (int j = 0; j < GW; ++j)
+            if (cidx + j < ((a.convt_co > 0) ? a.convt_co : a.Cout)) yp[j] = v[j];
         } else {
-          half4 o;
+          half_t* yp = (half_t*)a.y + yoff;
+          if (GW == 8) {
+            half8 o;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
-          *(half4*)yp = o;
+            for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+            *(half8*)yp = o;
+          } else {
+            half4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+            *(half4*)yp = o;
+          }
         }
       }
     }
   }
+  // every LDS-DMA this wave issued was waited for by the last kstep's vmcnt(0): no DMA can land after exit
 }
+
+int g_num_cus = 0;
 
 template <int MT, int NT, int WCH, int WPX>
 int launch_variant(const ConvArgs& a, hipStream_t s) {
@@ -278,7 +348,23 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (BCH + BPX) * BK * 2;
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;
   const int tiles_px = (a.M + BPX - 1) / BPX;
-  const dim3 grid(tiles_ch * tiles_px), block(256);
+  if (g_num_cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+    g_num_cus = prop.multiProcessorCount;
+  }
+  // One tile per block by default.  A persistent grid (CUs x resident blocks, loader cursor crossing
+  // tile boundaries) is supported by the kernel but measured SLOWER on MI355X for every layer of this
+  // network (fewer resident waves, epilogue-store drain on the next tile's first vmcnt(0)); it is kept
+  // behind dbg bit 64 for experiments.
+  int grid_x = tiles_ch * tiles_px;
+  if (a.dbg & 64) {
+    int per_cu = (160 * 1024) / LDS;
+    if (per_cu > 2) per_cu = 2;
+    if (grid_x > g_num_cus * per_cu) grid_x = g_num_cus * per_cu;
+  }
+  const dim3 grid(grid_x), block(256);
   hipError_t e;
   if (a.ksize == 1) {
     auto k = conv_igemm_kernel<MT, NT, WCH, WPX, 1>;
@@ -313,7 +399,9 @@ int conv_pick_tile(int cout, long M) {
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s) {
   if (a.ksize != 1 && a.ksize != 3) return -1;
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
-  int tile = force_tile;
+  if (a.M >= (1 << 24)) return -1;  // fast_divmod range
+  int tile = force_tile & 0xff;
+  if (force_tile < 0) tile = -1;
   if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
   switch (tile) {
     case TILE_128x128: return launch_variant<4, 4, 2, 2>(a, s);

@@ -47,6 +47,14 @@ CONV_CASES = [
     (2, 20, 20, 128, 128, 3, 1, 1, False, 3),       # forced 64x256 tile
     (2, 20, 20, 64, 64, 1, 1, 0, False, 0),         # forced 128x128 tile with Cout=64
     (4, 80, 80, 128, 128, 3, 1, 1, True, -1),       # many tiles
+    # halo-tile 3x3 kernel (tile id 16)
+    (2, 32, 32, 64, 64, 3, 1, 1, False, 16),        # single chunk, 64-ch variant
+    (2, 32, 48, 64, 64, 3, 1, 1, True, 16),
+    (2, 32, 32, 128, 128, 3, 1, 1, True, 16),       # two chunks, 128-ch variant
+    (1, 80, 80, 128, 224, 3, 1, 1, False, 16),      # ragged channel tile (224 = 128 + 96)
+    (2, 48, 32, 192, 64, 3, 1, 0, False, 16),       # 3 chunks, no act
+    (2, 72, 56, 64, 64, 3, 1, 1, True, 16),         # partial spatial tiles (72 = 4.5 x 16, 56 = 3.5 x 16)
+    (1, 160, 160, 128, 128, 3, 1, 1, False, 16),
 ]
 
 
