@@ -37,10 +37,11 @@ struct ConvArgs {
   int convt_co;        // >0: ConvTranspose 2x2/s2 pixel-shuffle store with Co = convt_co
   const half_t* zero;  // >=16 bytes of zeros in device memory (source for padded taps)
   int dbg;             // ablation switches for profiling experiments (0 in production)
+  unsigned long long* stamps;  // diagnostic builds: per-block s_memtime stamps (nullptr in production)
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_HALO = 16 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18 };
 
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s);
 // tile heuristic: cout = (virtual) output channels, M = output pixels of the whole batch
@@ -51,7 +52,7 @@ int conv_kpad(int cin, int ksize);
 
 // 3x3 stride-1 halo-tile kernel (conv3x3_halo.hip)
 bool conv3x3_halo_ok(const ConvArgs& a);
-int launch_conv3x3_halo(const ConvArgs& a, hipStream_t s);
+int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // variant 0 auto, 1: 16x16 px / 8 waves, 2: 8x16 px / 4 waves
 
 struct StemArgs {
   const uint8_t* x; int B, H, W;     // uint8 NHWC (B,H,W,3)

@@ -17,8 +17,10 @@
 //
 // Pipeline (one barrier per step, placed mid-step, fragments double-buffered in registers):
 //   top : ds_read ks=1(step s)            -> 16 MFMA ks=0(s)
-//   mid : vmcnt(0)+lgkmcnt(0)+barrier     -> ds_read ks=0(s+1); LDS-DMA weights(s+2), one patch piece
-//         of chunk c+1                    -> 16 MFMA ks=1(s)
+//   mid : counted vmcnt + barrier         -> ds_read ks=0(s+1); LDS-DMA weights(s+3) into a 4-deep ring,
+//         one patch piece of chunk c+1    -> 16 MFMA ks=1(s)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace m355 {
@@ -34,25 +36,32 @@ __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
-constexpr int TS = 16;            // output tile is TS x TS pixels
-constexpr int PW = TS + 2;        // patch width / height (18)
-constexpr int PROWS = 328;        // 18*18 = 324 patch pixels padded to 41 groups of 8 rows
-constexpr int PGROUPS = PROWS / 8;
+constexpr int TS = 16;            // output tile is TH rows x TS (16) pixels
+constexpr int PW = TS + 2;        // patch width (18)
 constexpr int ROWB = 128;         // one LDS row = 64 halves = one pixel's (or weight row's) 64-deep K chunk
-constexpr int PATCH_BYTES = PROWS * ROWB;
-constexpr int P_IT = (PGROUPS + 7) / 8;  // patch row groups per wave (6)
 
+// TH = tile rows (16 with 8 waves, 8 with 4 waves): NWAVES = WCH * WPX, NT * WPX = TH.
 template <int MT, int NT, int WCH, int WPX>
-__global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x, int tiles_y,
-                                                              int nchunks, int npatch) {
-  static_assert(WCH * WPX == 8 && NT * WPX == TS, "8 waves cover 16 rows");
+__global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const ConvArgs a, int tiles_x,
+                                                                         int tiles_y, int nchunks, int npatch) {
+  constexpr int NWAVES = WCH * WPX;
+  constexpr int TH = NT * WPX;
+  constexpr int PH = TH + 2;
+  constexpr int PGROUPS = (PH * PW + 7) / 8;          // patch pixels in groups of 8 LDS rows
+  constexpr int PATCH_BYTES = PGROUPS * 8 * ROWB;
+  constexpr int P_IT = (PGROUPS + NWAVES - 1) / NWAVES;  // patch row groups per wave
+  static_assert(NWAVES == 8 || NWAVES == 4, "4 or 8 waves");
   constexpr int BCH = WCH * MT * 16;
   constexpr int WBUF = BCH * ROWB;
-  constexpr int W_IT = BCH / 64;  // weight LDS-DMA instructions per wave per step (8 waves x 8 rows)
+  constexpr int NWB = (WCH * WPX == 8) ? 4 : 2;  // weight ring depth: a stage is in flight for NWB-1 steps
+  constexpr int W_IT = BCH / (NWAVES * 8);  // weight LDS-DMA instructions per wave per step
   static_assert(W_IT >= 1, "channel tile too small");
+  static_assert(P_IT <= 9, "one patch piece per tap step");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbase = smem + npatch * PATCH_BYTES;
 
+  unsigned long long st0 = 0, st1 = 0, st2 = 0;
+  if (a.stamps) st0 = __builtin_amdgcn_s_memtime();
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +83,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
   const int ty = rest % tiles_y;
   const int b = rest / tiles_y;
   const int ch_base = tile_ch * BCH;
-  const int y0 = ty * TS, x0 = tx * TS;
+  const int y0 = ty * TH, x0 = tx * TS;
   const int H = a.Hi, W = a.Wi;
   const half_t* const xb = a.x + (long)b * a.x_bstride;
 
@@ -83,11 +92,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
   unsigned pok = 0;
 #pragma unroll
   for (int i = 0; i < P_IT; ++i) {
-    const int j = wave + 8 * i;
+    const int j = wave + NWAVES * i;
     const int p = 8 * j + lrow;
     const int py = p / PW, px = p - py * PW;
     const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-    const bool in_patch = j < PGROUPS && p < PW * PW;
+    const bool in_patch = j < PGROUPS && p < PH * PW;
     const bool ok = in_patch && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     poff[i] = (iy * W + ix) * a.ldx + cc * 8;
     if (ok) pok |= 1u << i;
@@ -98,14 +107,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
   }
   auto issue_patch_piece = [&](int chunk, int i) {
     if ((pok >> i) & 1u)
-      glds16(xb + poff[i] + chunk * 64, smem + (chunk & (npatch - 1)) * PATCH_BYTES + (wave + 8 * i) * 1024);
+      glds16(xb + poff[i] + chunk * 64, smem + (chunk & (npatch - 1)) * PATCH_BYTES + (wave + NWAVES * i) * 1024);
   };
 
   // ---- weight loader state: LDS row R (MFMA-tile order) <- permuted source channel (see conv_igemm.hip)
   const half_t* wrow[W_IT];
 #pragma unroll
   for (int i = 0; i < W_IT; ++i) {
-    const int R = i * 64 + wave * 8 + lrow;
+    const int R = i * NWAVES * 8 + wave * 8 + lrow;
     const int blk = R / (MT * 16), Rl = R % (MT * 16);
     const int mt = Rl >> 4, r = Rl & 15;
     const int chl = (MT >= 2) ? ((mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3)) : r;
@@ -114,7 +123,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
   auto issue_weights = [&](int chunk, int tap, int buf) {
     const int koff = tap * a.Cin + chunk * 64;
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) glds16(wrow[i] + koff, wbase + buf * WBUF + (i * 64 + wave * 8) * ROWB);
+    for (int i = 0; i < W_IT; ++i) glds16(wrow[i] + koff, wbase + buf * WBUF + (i * NWAVES * 8 + wave * 8) * ROWB);
   };
 
   // ---- fragment addressing
@@ -146,9 +155,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
   // ---- prologue: patch of chunk 0, weights of steps 0 and 1
 #pragma unroll
   for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, i);
-  issue_weights(0, 0, 0);
-  issue_weights(0, 1, 1);
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_IT) : "memory");  // weights(1) may still fly
+#pragma unroll
+  for (int i = 0; i < NWB; ++i) issue_weights(0, i, i);  // steps 0..NWB-1 are taps of chunk 0 (NWB <= 9)
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 1) * W_IT) : "memory");  // stage 0 (+patch) landed
   __builtin_amdgcn_s_barrier();
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bcur[nt] = baddr(nt, 0, 0);
@@ -157,42 +166,68 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bf0[nt] = *(const half8*)(smem + bcur[nt]);
 
+  if (a.stamps) st1 = __builtin_amdgcn_s_memtime();
   const int nsteps = nchunks * 9;
   int chunk = 0, tap = 0;  // of step s
   for (int s = 0; s < nsteps; ++s) {
-    const char* wb = wbase + (s & 1) * WBUF;
-    const char* wn = wbase + ((s + 1) & 1) * WBUF;
+    const char* wb = wbase + (s & (NWB - 1)) * WBUF;
+    const char* wn = wbase + ((s + 1) & (NWB - 1)) * WBUF;
+    // half 1: 8 MFMA ks=0 | ds_read ks=1 fragments | 8 MFMA ks=0.  (Reads are placed BETWEEN MFMA groups
+    // because hipcc waits lgkmcnt(0) at the first MFMA after a loop back-edge / branchy region: with the
+    // reads issued half a group earlier they have always landed by then.)
+#pragma unroll
+    for (int mt = 0; mt < MT / 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0[mt], bf0[nt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) af1[mt] = *(const half8*)(wb + (aoff[mt] ^ 64));
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bf1[nt] = *(const half8*)(smem + (bcur[nt] ^ 64));
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int mt = MT / 2; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0[mt], bf0[nt], acc[mt][nt], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    // weights(s+1) and every older LDS-DMA must have landed; the NWB-2 younger weight stages may fly
+    if (s + NWB - 1 < nsteps)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 2) * W_IT) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    // (chunk, tap) of steps s+1 and s+2
+    // (chunk, tap) of step s+1 and of step s+NWB (whose weights go into the buffer step s just released)
     int c1 = chunk, t1 = tap + 1;
     if (t1 == 9) { t1 = 0; ++c1; }
-    int c2 = c1, t2 = t1 + 1;
-    if (t2 == 9) { t2 = 0; ++c2; }
-    // ks=0 fragments of step s+1 (past the last step this reads stale bytes that are never used)
+    int cN = chunk, tN = tap + NWB;
+    if (tN >= 9) { tN -= 9; ++cN; }
+    // half 2: 8 MFMA ks=1 | LDS-DMA issue for step s+2 (+ one patch piece of the next chunk), ds_read of the
+    // ks=0 fragments of step s+1 (past the last step they read stale bytes that are never used) | 8 MFMA ks=1.
+    // Everything between the MFMA groups runs in the shadow of the first group's execution.
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bcur[nt] = baddr(nt, c1, t1);
+    for (int mt = 0; mt < MT / 2; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(wn + aoff[mt]);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) bf0[nt] = *(const half8*)(smem + bcur[nt]);
-    if (s + 2 < nsteps) issue_weights(c2, t2, s & 1);
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[mt], bf1[nt], acc[mt][nt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + NWB < nsteps) issue_weights(cN, tN, s & (NWB - 1));
     if (tap < P_IT && chunk + 1 < nchunks) {
 #pragma unroll
       for (int i = 0; i < P_IT; ++i)
         if (i == tap) issue_patch_piece(chunk + 1, i);
     }
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt) bcur[nt] = baddr(nt, c1, t1);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(wn + aoff[mt]);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bf0[nt] = *(const half8*)(smem + bcur[nt]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = MT / 2; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[mt], bf1[nt], acc[mt][nt], 0, 0, 0);
@@ -200,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
     tap = t1;
   }
 
+  if (a.stamps) st2 = __builtin_amdgcn_s_memtime();
   // ---- epilogue (bias, SiLU, residual, fp16 pack, 16-byte stores at a channel offset)
   constexpr int GROUPS = (MT >= 2) ? MT / 2 : 1;
   constexpr int GW = (MT >= 2) ? 8 : 4;
@@ -254,43 +290,61 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const ConvArgs a, 
       }
     }
   }
+  if (a.stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = a.stamps + (long)blockIdx.x * 4;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+  }
 }
 
 template <int MT, int NT, int WCH, int WPX>
 int launch_halo_variant(const ConvArgs& a, hipStream_t s) {
   constexpr int BCH = WCH * MT * 16;
-  const int tiles_x = (a.Wi + TS - 1) / TS, tiles_y = (a.Hi + TS - 1) / TS;
+  constexpr int TH = NT * WPX;
+  constexpr int PGROUPS = ((TH + 2) * PW + 7) / 8;
+  const int tiles_x = (a.Wi + TS - 1) / TS, tiles_y = (a.Hi + TH - 1) / TH;
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;
   const int nchunks = a.Cin / 64;
   const int npatch = nchunks > 1 ? 2 : 1;
   const int B = a.M / (a.Ho * a.Wo);
-  const int lds = npatch * PATCH_BYTES + 2 * BCH * ROWB;
+  const int lds = npatch * PGROUPS * 8 * ROWB + ((WCH * WPX == 8) ? 4 : 2) * BCH * ROWB;
   auto k = conv3x3_halo_kernel<MT, NT, WCH, WPX>;
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k, dim3(B * tiles_y * tiles_x * tiles_ch), dim3(512), lds, s, a, tiles_x, tiles_y, nchunks,
-                     npatch);
+  hipLaunchKernelGGL(k, dim3(B * tiles_y * tiles_x * tiles_ch), dim3(WCH * WPX * 64), lds, s, a, tiles_x, tiles_y,
+                     nchunks, npatch);
   return (int)hipGetLastError();
 }
 
 }  // namespace
 
-// Eligibility: 3x3 stride 1 pad 1, fp16 output, Cin a multiple of 64, Cout >= 64, and the 16x16 tiling
+// Eligibility: 3x3 stride 1 pad 1, fp16 output, Cin a multiple of 64, Cout >= 64, and the 16-wide tiling
 // wastes at most 30 % of the computed pixels.
 bool conv3x3_halo_ok(const ConvArgs& a) {
   if (a.ksize != 3 || a.stride != 1 || a.pad != 1 || a.out_f32 || a.convt_co > 0) return false;
   if (a.Cin % 64 || a.Cout < 64 || a.Cout % 8 || a.ldx % 8 || a.ldy % 8) return false;
   if (a.Ho != a.Hi || a.Wo != a.Wi) return false;
-  const long covered = (long)((a.Hi + TS - 1) / TS) * TS * ((a.Wi + TS - 1) / TS) * TS;
+  const long covered = (long)((a.Hi + 7) / 8) * 8 * ((a.Wi + TS - 1) / TS) * TS;
   return covered * 10 <= (long)a.Hi * a.Wi * 13;
 }
 
-int launch_conv3x3_halo(const ConvArgs& a, hipStream_t s) {
+// variant: 0 = auto, 1 = 8 waves / 16x16 px, 2 = 4 waves / 8x16 px
+int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s) {
   if (!conv3x3_halo_ok(a)) return -1;
-  if (a.Cout > 64) return launch_halo_variant<4, 4, 2, 4>(a, s);  // 128 ch x 256 px, wave 64 ch x 64 px
-  return launch_halo_variant<4, 2, 1, 8>(a, s);                   //  64 ch x 256 px, wave 64 ch x 32 px
+  if (variant == 0) {
+    const char* ev = getenv("M355_HALO_VARIANT");
+    variant = ev ? atoi(ev) : 2;  // measured: the 4-wave variant (two blocks per CU) wins on every layer
+    if (variant != 1 && variant != 2) variant = 2;
+  }
+  if (variant == 1) {
+    if (a.Cout > 64) return launch_halo_variant<4, 4, 2, 4>(a, s);  // 128 ch x 256 px, wave 64 ch x 64 px
+    return launch_halo_variant<4, 2, 1, 8>(a, s);                   //  64 ch x 256 px, wave 64 ch x 32 px
+  }
+  if (a.Cout > 64) return launch_halo_variant<4, 4, 2, 2>(a, s);    // 128 ch x 128 px, wave 64 ch x 64 px
+  return launch_halo_variant<4, 2, 1, 4>(a, s);                     //  64 ch x 128 px, wave 64 ch x 32 px
 }
 
 }  // namespace m355

@@ -26,6 +26,8 @@
 // offset of a wider NHWC buffer (zero-copy concat); weight rows are permuted by the loader so that
 // lane group g owns channels {g*8..g*8+7} (+32): per store instruction every pixel receives one
 // contiguous 64-byte run.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace m355 {
@@ -390,7 +392,11 @@ int conv_cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 int conv_kpad(int cin, int ksize) { return (cin * ksize * ksize + BK - 1) / BK * BK; }
 
 int conv_pick_tile(int cout, long M) {
-  (void)M;
+  // small pixel counts (20x20 maps at batch 32): a 128x128 grid leaves most CUs with <= 1 block; halve the
+  // channel tile to double the number of blocks
+  const char* ev = getenv("M355_SMALLM");
+  const long thr = ev ? atol(ev) : 300;  // measured sweep 0/300/600/1000 on MI355X: 300 is best
+  if (cout > 64 && M * ((cout + 127) / 128) / 128 < thr) return TILE_64x128;
   if (cout > 64) return TILE_128x128;
   if (cout > 32) return TILE_64x128;
   return TILE_32x256;

@@ -657,7 +657,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           a.res = tr.p + op.res.off; a.r_bstride = (long)tr.H * tr.W * tr.C; a.ldr = tr.C;
         }
         a.M = B * a.Ho * a.Wo;
-        rc = (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, s) : launch_conv_igemm(a, op.tile, s);
+        rc = (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s) : launch_conv_igemm(a, op.tile, s);
         break;
       }
       case OP_POOL: {
@@ -814,10 +814,26 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   }
   a.M = B * a.Ho * a.Wo;
   a.dbg = force_tile >= 0 ? (force_tile >> 8) : 0;
+  unsigned long long* d_st = nullptr;
+  const char* st_path = getenv("M355_STAMPS");
+  const size_t st_n = (size_t)1 << 20;
+  if (st_path) {
+    HIP_TRYG(hipMalloc((void**)&d_st, st_n * 8));
+    HIP_TRYG(hipMemset(d_st, 0, st_n * 8));
+    a.stamps = d_st;
+  }
   int rc = 0;
   for (int rep = 0; rep < (a.dbg ? 5 : 1); ++rep)
-    rc = ((force_tile & 0xff) == TILE_HALO && force_tile >= 0) ? launch_conv3x3_halo(a, s) : launch_conv_igemm(a, force_tile, s);
+    rc = (force_tile >= 0 && (force_tile & 0xff) >= TILE_HALO) ? launch_conv3x3_halo(a, (force_tile & 0xff) - TILE_HALO, s)
+                                                              : launch_conv_igemm(a, force_tile, s);
   hipError_t se = hipStreamSynchronize(s);
+  if (st_path && se == hipSuccess) {
+    std::vector<unsigned long long> h(st_n);
+    (void)hipMemcpy(h.data(), d_st, st_n * 8, hipMemcpyDeviceToHost);
+    FILE* f = fopen(st_path, "wb");
+    if (f) { fwrite(h.data(), 8, st_n, f); fclose(f); }
+  }
+  if (d_st) (void)hipFree(d_st);
   (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dz);
   if (rc != 0) return set_err(M355_ERR_HIP, "conv launch failed: " + std::to_string(rc));
   if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("conv kernel: ") + hipGetErrorString(se));

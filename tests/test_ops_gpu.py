@@ -55,6 +55,13 @@ CONV_CASES = [
     (2, 48, 32, 192, 64, 3, 1, 0, False, 16),       # 3 chunks, no act
     (2, 72, 56, 64, 64, 3, 1, 1, True, 16),         # partial spatial tiles (72 = 4.5 x 16, 56 = 3.5 x 16)
     (1, 160, 160, 128, 128, 3, 1, 1, False, 16),
+    # both halo variants explicitly: 17 = 8 waves / 16x16 px, 18 = 4 waves / 8x16 px
+    (2, 32, 32, 128, 128, 3, 1, 1, True, 17),
+    (2, 72, 56, 64, 64, 3, 1, 1, True, 17),
+    (1, 80, 80, 128, 224, 3, 1, 1, False, 17),
+    (2, 32, 32, 128, 128, 3, 1, 1, True, 18),
+    (2, 72, 56, 64, 64, 3, 1, 1, True, 18),
+    (1, 80, 80, 128, 224, 3, 1, 1, False, 18),
 ]
 
 
