@@ -1,0 +1,141 @@
+"""CPU tests of the product's host logic (no GPU, no compute through the engine)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import yolov8_seg_oracle as orc
+from defectdetection_viaobjectdetection_amd import preprocess as pp
+from defectdetection_viaobjectdetection_amd import spec
+from defectdetection_viaobjectdetection_amd.results import Boxes, Masks, Results
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("scale,nc", [("n", 1), ("s", 1), ("m", 1), ("s", 80)])
+def test_state_dict_matches_oracle_module(scale, nc):
+    """Host spec == the oracle's nn.Module state dict: same key set, same shapes (A.1 naming)."""
+    sd = spec.init_state_dict(scale, nc)
+    osd = orc.SegmentationModel(scale, nc).state_dict()
+    assert set(sd) == set(osd)
+    for k in sd:
+        assert tuple(sd[k].shape) == tuple(osd[k].shape), k
+    assert spec.count_parameters(sd) == orc.count_parameters(orc.SegmentationModel(scale, nc))
+    assert spec.state_dict_keys(scale, nc) == [k for k in spec.state_dict_keys(scale, nc) if k in osd]
+
+
+def test_default_init_head_biases():
+    sd = spec.init_state_dict("s", 1)
+    o = orc.SegmentationModel("s", 1).state_dict()
+    for l in range(3):
+        assert torch.equal(sd[f"model.22.cv2.{l}.2.bias"], o[f"model.22.cv2.{l}.2.bias"])
+        assert torch.allclose(sd[f"model.22.cv3.{l}.2.bias"], o[f"model.22.cv3.{l}.2.bias"])
+
+
+def test_fold_bn_equals_conv_bn_eval():
+    sd = spec.synthetic_state_dict("n", 1, seed=3)
+    s = [c for c in spec.conv_specs("n", 1) if c.name == "model.2.m.0.cv1"][0]
+    w, b = spec.fold_bn(sd, s)
+    x = torch.randn(2, s.cin, 9, 11, generator=torch.Generator().manual_seed(0))
+    ref = F.batch_norm(F.conv2d(x, sd[f"{s.name}.conv.weight"], None, 1, 1), sd[f"{s.name}.bn.running_mean"],
+                       sd[f"{s.name}.bn.running_var"], sd[f"{s.name}.bn.weight"], sd[f"{s.name}.bn.bias"], False, 0.0,
+                       spec.BN_EPS)
+    assert torch.allclose(F.conv2d(x, w, b, 1, 1), ref, atol=1e-5, rtol=1e-5)
+
+
+def test_synthetic_weights_are_seeded():
+    a, b = spec.synthetic_state_dict("n", 1, seed=5), spec.synthetic_state_dict("n", 1, seed=5)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    c = spec.synthetic_state_dict("n", 1, seed=6)
+    assert not torch.equal(a["model.0.conv.weight"], c["model.0.conv.weight"])
+
+
+def test_letterbox_matches_oracle_restatement():
+    """Two independent restatements of A.2 (product host code vs oracle) agree bit for bit."""
+    img = pp.load_image(os.path.join(GOLDEN, "bscans", "787-226_03_Ch-0_81.png"))
+    assert img.shape == (320, 320, 3) and img.dtype == np.uint8
+    for shape in ((640, 640), (320, 320), (480, 640)):
+        a = pp.letterbox(img, shape)
+        b, _, _ = orc.letterbox(img, shape)
+        assert np.array_equal(a, b), shape
+    wide = np.random.default_rng(0).integers(0, 256, (100, 200, 3), dtype=np.uint8)
+    assert np.array_equal(pp.letterbox(wide, (640, 640)), orc.letterbox(wide, (640, 640))[0])
+    # auto (min-rectangle) mode
+    r, unpad, pads, out = pp.letterbox_shape((100, 200), (640, 640), auto=True)
+    assert out == (320, 640) and pads == (0, 0, 0, 0)
+    assert np.array_equal(pp.letterbox(wide, (640, 640), auto=True), orc.letterbox(wide, (640, 640), auto=True)[0])
+
+
+def test_scale_boxes_matches_oracle():
+    b = np.array([[100.0, 180.0, 300.0, 400.0], [-5.0, 0.0, 700.0, 700.0]], np.float32)
+    for orig in ((100, 200), (320, 320), (481, 333)):
+        assert np.array_equal(pp.scale_boxes_to_original(b, (640, 640), orig), orc.scale_boxes((640, 640), b, orig))
+
+
+def test_expand_sources_directory_and_array():
+    imgs, paths = pp.expand_sources(os.path.join(GOLDEN, "bscans"))
+    assert len(imgs) == 4 and all(p.endswith(".png") for p in paths) and paths == sorted(paths)
+    imgs, paths = pp.expand_sources([np.zeros((8, 8), np.uint8)])
+    assert imgs[0].shape == (8, 8, 3)
+    with pytest.raises(FileNotFoundError):
+        pp.expand_sources("does_not_exist.png")
+
+
+def _results():
+    orig = np.zeros((320, 320, 3), np.uint8)
+    boxes = torch.tensor([[10.0, 20.0, 110.0, 220.0, 0.9, 0.0], [50.0, 60.0, 70.0, 90.0, 0.5, 0.0]])
+    masks = torch.zeros((2, 640, 640), dtype=torch.uint8)
+    masks[0, 40:440, 20:220] = 1
+    masks[1, 120:180, 100:140] = 1
+    return Results(orig, "x.png", {0: "defect"}, boxes, masks, net_shape=(640, 640))
+
+
+def test_results_api_as_used_by_reference_scripts():
+    res = _results()
+    lines = []
+    for i, box in enumerate(res.boxes):                       # yolo/yolo_eval.py:30-35
+        x1, y1, x2, y2 = box.xyxy.tolist()[0]
+        lines.append((i, x1, y1, x2, y2, float(box.conf), int(box.cls)))
+    assert lines[0] == (0, 10.0, 20.0, 110.0, 220.0, pytest.approx(0.9), 0)
+    assert res.boxes[1].xyxy[0].cpu().numpy().tolist() == [50.0, 60.0, 70.0, 90.0]   # yolo_detector.py:48
+    res.names = {0: "FO"}                                       # yolo_folder_eval.py:26
+    img = res.plot()                                            # yolo_eval.py:37
+    assert img.shape == (320, 320, 3) and img.dtype == np.uint8 and img.any()
+    assert "FO" in res.verbose() and "2 FOs" in res.verbose()
+    assert "boxes" in str(res) and len(res) == 2
+    assert res.boxes.xywh[0].tolist() == [60.0, 120.0, 100.0, 200.0]
+    assert torch.allclose(res.boxes.xyxyn[0], torch.tensor([10 / 320, 20 / 320, 110 / 320, 220 / 320]))
+    polys = res.masks.xy
+    assert len(polys) == 2 and polys[0].shape[1] == 2
+    assert polys[0][:, 0].min() >= 9.5 and polys[0][:, 0].max() <= 110.5     # 640-space mask -> original pixels
+
+
+def test_results_save(tmp_path):
+    out = _results().save(str(tmp_path / "a" / "annot.jpg"))
+    assert os.path.getsize(out) > 0
+
+
+def test_yolo_facade_offline_behaviour(tmp_path):
+    from defectdetection_viaobjectdetection_amd.model import OfflineModelError, YOLO
+    with pytest.raises(OfflineModelError):
+        YOLO("yolov9c-seg.pt")                                  # yolo_seg_train.py:8 -- would download upstream
+    with pytest.raises(NotImplementedError):
+        YOLO("yolov9c-seg.yaml")                                # yolo_seg_train.py:7 -- next row N4
+    m = YOLO("yolov8n-seg.yaml")
+    assert m.scale == "n" and m.nc == 80 and m.info()[1] == 3409968
+    m.set_classes(1, {0: "defect"})
+    assert m.info()[1] == 3263811 and m.names == {0: "defect"}
+    p = m.save(str(tmp_path / "w" / "best.pt"))
+    m2 = YOLO(p)
+    assert m2.scale == "n" and m2.nc == 1 and m2.names == {0: "defect"}
+    assert all(torch.equal(m.state_dict[k], m2.state_dict[k]) for k in m.state_dict)
+    with pytest.raises(NotImplementedError):
+        m2.train(data="data-seg.yaml", epochs=1)
+
+
+def test_shim_import_surface():
+    import ultralytics
+    assert ultralytics.YOLO.__module__ == "defectdetection_viaobjectdetection_amd.model"
+    assert {"YOLO", "Results", "Boxes", "Masks"} <= set(ultralytics.__all__)
