@@ -149,6 +149,7 @@ def main():
                 achieved = d["bytes"] / (d["ms"] * 1e-3) / 1e9
                 roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
+            roof["traffic"] = pmc_traffic(dom)
             roof["launches_per_step"] = d["launches"] // max(sampled, 1)
             roof["event_sampled_steps"] = sampled
             roof["avg_launch_us"] = round(1e3 * d["ms"] / max(d["launches"], 1), 2)
@@ -165,6 +166,18 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_label):
+    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes of this same command
+    (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"].get(kernel_label)
+        return None if k is None else round(k["hbm_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def host_cores():
