@@ -56,7 +56,7 @@ int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // vari
 
 struct StemArgs {
   const uint8_t* x; int B, H, W;     // uint8 NHWC (B,H,W,3)
-  const float* w;                    // [27][Cout] fp32, already divided by 255
+  const half_t* w16;                 // [Cout][32] fp16: k = (kh*3+kw)*3+ci, rows 27..31 zero; NOT scaled by 1/255
   const float* bias;                 // [Cout]
   half_t* y; long y_bstride; int ldy; int Cout;
 };

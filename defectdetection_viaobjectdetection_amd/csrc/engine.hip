@@ -407,7 +407,7 @@ void annotate_ops(m355_engine* e) {
       case OP_STEM: {
         const PhysConv& p = e->phys[op.conv];
         const Tensor& to = e->tensors[op.out.t];
-        snprintf(op.kernel, sizeof(op.kernel), "stem_conv<k3s2,u8>");
+        snprintf(op.kernel, sizeof(op.kernel), "stem_conv<k3s2,u8,mfma>");
         op.flops = 2.0 * to.H * to.W * p.cout * 27;
         op.bytes = (double)op.Hi * op.Wi * 3 + (double)to.H * to.W * p.cout * 2;
         op.wbytes = 28.0 * p.cout * 4;
@@ -560,14 +560,14 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
   const m355_conv_info& ci = e->convs[idx];
   PhysConv& p = e->phys[e->conv_phys[idx]];
   const int row0 = e->conv_phys_off[idx];
-  if (ci.cin == 3) {  // stem: [27][cout] fp32, scaled by 1/255
-    std::vector<float> sw(27 * ci.cout);
+  if (ci.cin == 3) {  // stem: [cout][32] fp16, k = (kh*3+kw)*3+c; 1/255 is applied in the kernel's epilogue
+    std::vector<half_t> sw((size_t)ci.cout * 32, (half_t)0.f);
     for (int co = 0; co < ci.cout; ++co)
       for (int c = 0; c < 3; ++c)
         for (int kh = 0; kh < 3; ++kh)
           for (int kw = 0; kw < 3; ++kw)
-            sw[((kh * 3 + kw) * 3 + c) * ci.cout + co] = w[((co * 3 + c) * 3 + kh) * 3 + kw] * (1.0f / 255.0f);
-    HIP_TRY(e, hipMemcpy(p.stem_w, sw.data(), sw.size() * sizeof(float), hipMemcpyHostToDevice));
+            sw[(size_t)co * 32 + (kh * 3 + kw) * 3 + c] = (half_t)w[((co * 3 + c) * 3 + kh) * 3 + kw];
+    HIP_TRY(e, hipMemcpy(p.stem_w, sw.data(), sw.size() * sizeof(half_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
   } else if (ci.transposed) {  // (cin,cout,2,2) -> virtual channel (dy*2+dx)*cout + co, K = cin
     std::vector<half_t> rows((size_t)4 * ci.cout * p.Kpad, (half_t)0.f);
@@ -617,7 +617,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         const Tensor& to = e->tensors[op.out.t];
         StemArgs a{};
         a.x = (const uint8_t*)d_in; a.B = B; a.H = op.Hi; a.W = op.Wi;
-        a.w = p.stem_w; a.bias = p.bias;
+        a.w16 = (const half_t*)p.stem_w; a.bias = p.bias;
         a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C; a.Cout = p.cout;
         rc = launch_stem(a, s);
         break;
@@ -856,19 +856,20 @@ int m355_stem_fwd(const void* d_in, int B, int H, int W, const float* h_w, const
                   void* stream) {
   if (!d_in || !h_w || !h_bias || !d_y) return set_err(M355_ERR_INVALID, "null pointer");
   hipStream_t s = (hipStream_t)stream;
-  std::vector<float> sw(27 * cout);
+  std::vector<half_t> sw((size_t)cout * 32, (half_t)0.f);
   for (int co = 0; co < cout; ++co)
     for (int c = 0; c < 3; ++c)
       for (int kh = 0; kh < 3; ++kh)
         for (int kw = 0; kw < 3; ++kw)
-          sw[((kh * 3 + kw) * 3 + c) * cout + co] = h_w[((co * 3 + c) * 3 + kh) * 3 + kw] * (1.0f / 255.0f);
-  float *dw = nullptr, *db = nullptr;
-  HIP_TRYG(hipMalloc((void**)&dw, sw.size() * sizeof(float)));
+          sw[(size_t)co * 32 + (kh * 3 + kw) * 3 + c] = (half_t)h_w[((co * 3 + c) * 3 + kh) * 3 + kw];
+  half_t* dw = nullptr;
+  float* db = nullptr;
+  HIP_TRYG(hipMalloc((void**)&dw, sw.size() * sizeof(half_t)));
   HIP_TRYG(hipMalloc((void**)&db, cout * sizeof(float)));
-  HIP_TRYG(hipMemcpy(dw, sw.data(), sw.size() * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(dw, sw.data(), sw.size() * sizeof(half_t), hipMemcpyHostToDevice));
   HIP_TRYG(hipMemcpy(db, h_bias, cout * sizeof(float), hipMemcpyHostToDevice));
   StemArgs a{};
-  a.x = (const uint8_t*)d_in; a.B = B; a.H = H; a.W = W; a.w = dw; a.bias = db;
+  a.x = (const uint8_t*)d_in; a.B = B; a.H = H; a.W = W; a.w16 = dw; a.bias = db;
   a.y = (half_t*)d_y; a.y_bstride = (long)(H / 2) * (W / 2) * cout; a.ldy = cout; a.Cout = cout;
   const int rc = launch_stem(a, s);
   hipError_t se = hipStreamSynchronize(s);

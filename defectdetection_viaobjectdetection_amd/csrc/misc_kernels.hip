@@ -14,48 +14,79 @@ __device__ __forceinline__ float silu_f(float v) {
 
 // ---------------------------------------------------------------------------------------------
 // Stem: 3x3 stride-2 pad-1 conv on uint8 NHWC (B,H,W,3) -> fp16 NHWC (B,H/2,W/2,COUT), + bias + SiLU.
-// K = 27 is too short for the LDS-DMA implicit GEMM; the layer is HBM-bound (1.2 MB in, COUT*0.2 MB
-// out per 640x640 image), so one thread computes one output pixel for all COUT channels on the VALU
-// with wave-uniform weights (scalar loads).  Weights already hold the 1/255 input scaling.
+// HBM-bound layer (1.2 MB in, COUT*0.2 MB out per 640x640 image).  K = 27 (padded to 32) is one
+// v_mfma_f32_16x16x32_f16 per 16 channels x 16 pixels: lane (pixel l&15, k-group l>>4) gathers its 8 taps
+// as single bytes straight from global memory (the 3x3x3 windows of neighbouring pixels overlap, so the
+// bytes come out of L1), converts them to fp16 (0..255 is exact) and feeds them as the B operand; the
+// weights [COUT][32] fp16 (unscaled; 1/255 is applied to the fp32 accumulator) are the A operand, loaded
+// once per wave.  A wave walks 16-pixel row segments with a grid stride.
 // ---------------------------------------------------------------------------------------------
 template <int COUT>
 __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
+  constexpr int MT = COUT / 16;
+  const int lane = threadIdx.x & 63;
+  const int l15 = lane & 15, g = lane >> 4;
   const int Ho = a.H >> 1, Wo = a.W >> 1;
-  const long total = (long)a.B * Ho * Wo;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int b = (int)(idx / (Ho * Wo));
-  const int pix = (int)(idx - (long)b * Ho * Wo);
-  const int ho = pix / Wo, wo = pix - ho * Wo;
-  float acc[COUT];
+  const int segs = (Wo + 15) >> 4;                 // 16-pixel segments per output row
+  const long total = (long)a.B * Ho * segs;
+  const long wave_id = ((long)blockIdx.x * 256 + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * 256) >> 6;
+
+  half8 wf[MT];
 #pragma unroll
-  for (int c = 0; c < COUT; ++c) acc[c] = a.bias[c];
-  const uint8_t* xb = a.x + (long)b * a.H * a.W * 3;
+  for (int mt = 0; mt < MT; ++mt) wf[mt] = *(const half8*)(a.w16 + (mt * 16 + l15) * 32 + g * 8);
+  float bias[MT][4];
 #pragma unroll
-  for (int kh = 0; kh < 3; ++kh) {
-    const int hi = 2 * ho - 1 + kh;
-    const bool hv = (unsigned)hi < (unsigned)a.H;
+  for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int kw = 0; kw < 3; ++kw) {
-      const int wi = 2 * wo - 1 + kw;
-      const bool v = hv && (unsigned)wi < (unsigned)a.W;
-      const uint8_t* p = xb + ((long)hi * a.W + wi) * 3;
+    for (int j = 0; j < 4; ++j) bias[mt][j] = a.bias[mt * 16 + g * 4 + j];
+  // this lane's 8 taps: k = 8g + j -> (kh, q = kw*3 + ci); byte offset relative to (row 2ho-1, col (2wo-1)*3)
+  int toff[8];
+  int tkh[8];
+  bool tok[8];
+  int tkw[8];
 #pragma unroll
-      for (int ci = 0; ci < 3; ++ci) {
-        const float xv = v ? (float)p[ci] : 0.f;
-        const float* wr = a.w + ((kh * 3 + kw) * 3 + ci) * COUT;
+  for (int j = 0; j < 8; ++j) {
+    const int k = g * 8 + j;
+    const int kh = k / 9, q = k - kh * 9;
+    tkh[j] = kh;
+    tkw[j] = q / 3;
+    tok[j] = k < 27;
+    toff[j] = kh * a.W * 3 + q;
+  }
+  const float inv255 = 1.0f / 255.0f;
+  for (long t = wave_id; t < total; t += nwaves) {
+    const int seg = (int)(t % segs);
+    const long r = t / segs;
+    const int ho = (int)(r % Ho);
+    const int b = (int)(r / Ho);
+    const int wo = seg * 16 + l15;
+    const bool pv = wo < Wo;
+    const int hi0 = 2 * ho - 1, wi0 = 2 * wo - 1;
+    const uint8_t* base = a.x + ((long)b * a.H + hi0) * a.W * 3 + (long)wi0 * 3;
+    half8 xf;
 #pragma unroll
-        for (int c = 0; c < COUT; ++c) acc[c] = __builtin_fmaf(xv, wr[c], acc[c]);
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = pv && tok[j] && (unsigned)(hi0 + tkh[j]) < (unsigned)a.H && (unsigned)(wi0 + tkw[j]) < (unsigned)a.W;
+      const unsigned v = ok ? (unsigned)base[toff[j]] : 0u;
+      xf[j] = (half_t)(float)v;
+    }
+    float4v acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt] = float4v{0.f, 0.f, 0.f, 0.f};
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mt], xf, acc[mt], 0, 0, 0);
+    }
+    if (pv) {
+      half_t* yp = a.y + (long)b * a.y_bstride + ((long)ho * Wo + wo) * a.ldy;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (half_t)silu_f(acc[mt][j] * inv255 + bias[mt][j]);
+        *(half4*)(yp + mt * 16 + g * 4) = o;
       }
     }
-  }
-  half_t* yp = a.y + (long)b * a.y_bstride + (long)pix * a.ldy;
-#pragma unroll
-  for (int c0 = 0; c0 < COUT; c0 += 8) {
-    half8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (half_t)silu_f(acc[c0 + j]);
-    *(half8*)(yp + c0) = o;
   }
 }
 
@@ -122,21 +153,34 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const half_t* x, long x
 
 // ---------------------------------------------------------------------------------------------
 // Detect decode (A9).  raw (B,A,64+nc+nm) f32 -> preds (B,A,4+nc+nm) f32.
-// Four lanes per anchor: lane q computes side q's DFL expectation (softmax over 16 bins . arange(16)),
-// the quad exchanges l,t,r,b by DPP-class shuffles, lane q writes output q of (cx,cy,w,h)*stride, and
-// the quad copies sigmoid(cls) and the mask coefficients.
+// One block = 64 consecutive anchors: their raw rows are one contiguous span -> coalesced 16-byte loads
+// into LDS; four lanes per anchor compute the DFL expectations (softmax over 16 bins . arange(16)) and
+// exchange l,t,r,b by quad shuffles; outputs are staged in LDS and leave as coalesced 16-byte stores.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void head_decode_kernel(const float* raw, int B, int A, int w3, int w4, int w5,
-                                                          int n3, int n4, int nc, int nm, float* preds) {
-  const long gid = (long)blockIdx.x * 256 + threadIdx.x;
-  const long anchor_g = gid >> 2;
-  const int q = (int)(gid & 3);
-  const bool valid = anchor_g < (long)B * A;
-  const long ag = valid ? anchor_g : 0;
-  const int a = (int)(ag % A);
+constexpr int DEC_ANCHORS = 64;
+
+__global__ __launch_bounds__(256) void head_decode_kernel(const float* raw, long total_anchors, int A, int w3, int w4,
+                                                          int w5, int n3, int n4, int nc, int nm, float* preds) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int wi = 64 + nc + nm, wo = 4 + nc + nm;
-  const float* rp = raw + ag * wi;
-  // DFL: softmax-expectation over this side's 16 logits
+  float* sin = dsm;                          // DEC_ANCHORS * wi
+  float* sout = dsm + DEC_ANCHORS * wi;      // DEC_ANCHORS * wo
+  const long a0 = (long)blockIdx.x * DEC_ANCHORS;
+  const int na = (int)((total_anchors - a0 < DEC_ANCHORS) ? (total_anchors - a0) : DEC_ANCHORS);
+  const float* src = raw + a0 * wi;
+  const int nin = na * wi;
+  // a0 is a multiple of 64, so a0*wi*4 bytes is 16-byte aligned for any wi
+  for (int i = threadIdx.x * 4; i < nin; i += 256 * 4) {
+    if (i + 4 <= nin) {
+      *(float4v*)(sin + i) = *(const float4v*)(src + i);
+    } else {
+      for (int j = i; j < nin; ++j) sin[j] = src[j];
+    }
+  }
+  __syncthreads();
+  const int al_blk = threadIdx.x >> 2, q = threadIdx.x & 3;
+  const bool valid = al_blk < na;
+  const float* rp = sin + (valid ? al_blk : 0) * wi;
   float v[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = rp[q * 16 + j];
@@ -151,7 +195,7 @@ __global__ __launch_bounds__(256) void head_decode_kernel(const float* raw, int 
     sw += e * (float)j;
   }
   const float d = sw / se;
-  // anchor point and stride
+  const int a = (int)((a0 + (valid ? al_blk : 0)) % A);
   int al = a, gw = w3;
   float stride = 8.f;
   if (a >= n3 + n4) {
@@ -170,21 +214,34 @@ __global__ __launch_bounds__(256) void head_decode_kernel(const float* raw, int 
   else if (q == 1) o = (y1 + y2) * 0.5f;
   else if (q == 2) o = x2 - x1;
   else o = y2 - y1;
-  if (!valid) return;
-  float* pp = preds + ag * wo;
-  pp[q] = o * stride;
-  for (int j = q; j < nc; j += 4) {
-    const float z = rp[64 + j];
-    pp[4 + j] = 1.0f / (1.0f + __expf(-z));
+  if (valid) {
+    float* pp = sout + al_blk * wo;
+    pp[q] = o * stride;
+    for (int j = q; j < nc; j += 4) {
+      const float z = rp[64 + j];
+      pp[4 + j] = 1.0f / (1.0f + __expf(-z));
+    }
+    for (int j = q; j < nm; j += 4) pp[4 + nc + j] = rp[64 + nc + j];
   }
-  for (int j = q; j < nm; j += 4) pp[4 + nc + j] = rp[64 + nc + j];
+  __syncthreads();
+  float* dst = preds + a0 * wo;
+  const int nout = na * wo;
+  for (int i = threadIdx.x * 4; i < nout; i += 256 * 4) {
+    if (i + 4 <= nout) {
+      *(float4v*)(dst + i) = *(const float4v*)(sout + i);
+    } else {
+      for (int j = i; j < nout; ++j) dst[j] = sout[j];
+    }
+  }
 }
 
 }  // namespace
 
 int launch_stem(const StemArgs& a, hipStream_t s) {
-  const long total = (long)a.B * (a.H / 2) * (a.W / 2);
-  const dim3 grid((unsigned)((total + 255) / 256)), block(256);
+  const long total = (long)a.B * (a.H / 2) * ((a.W / 2 + 15) / 16);  // one wave per 16-pixel segment
+  long blocks = (total + 3) / 4;
+  if (blocks > 256 * 32) blocks = 256 * 32;
+  const dim3 grid((unsigned)blocks), block(256);
   switch (a.Cout) {
     case 16: hipLaunchKernelGGL(stem_kernel<16>, grid, block, 0, s, a); break;
     case 32: hipLaunchKernelGGL(stem_kernel<32>, grid, block, 0, s, a); break;
@@ -226,9 +283,15 @@ int launch_head_decode(const float* raw, int B, int in_h, int in_w, int nc, int 
   const int h3 = in_h / 8, w3 = in_w / 8, h4 = in_h / 16, w4 = in_w / 16, h5 = in_h / 32, w5 = in_w / 32;
   const int n3 = h3 * w3, n4 = h4 * w4, n5 = h5 * w5;
   const int A = n3 + n4 + n5;
-  const long threads = (long)B * A * 4;
-  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, raw, B, A, w3,
-                     w4, w5, n3, n4, nc, nm, preds);
+  const long total = (long)B * A;
+  const size_t lds = (size_t)DEC_ANCHORS * ((64 + nc + nm) + (4 + nc + nm)) * sizeof(float);
+  if (lds > 160 * 1024) return -1;
+  if (lds > 64 * 1024) {  // many classes (nc = 80: 75 KB)
+    hipError_t e = hipFuncSetAttribute((const void*)head_decode_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(head_decode_kernel, dim3((unsigned)((total + DEC_ANCHORS - 1) / DEC_ANCHORS)), dim3(256), lds, s,
+                     raw, total, A, w3, w4, w5, n3, n4, nc, nm, preds);
   return (int)hipGetLastError();
 }
 

@@ -175,10 +175,7 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
   const int tiles = tiles_x * tiles_y;
   const long total = (long)prefix[B] * tiles;
   const float wr = (float)mw / (float)in_w, hr = (float)mh / (float)in_h;
-  const int up_y = in_h / mh, up_x = in_w / mw;  // 4
-  const float sy = (float)mh / (float)in_h, sx = (float)mw / (float)in_w;
-  const int out_w = 16 * up_x, out_h = 16 * up_y;  // 64 x 64 per tile
-  const int segs = out_w / 16;
+  constexpr int out_w = 64, out_h = 64, segs = 4;  // a 16x16 prototype tile covers 64 x 64 output pixels (x4)
   for (long item = blockIdx.x; item < total; item += gridDim.x) {
     const int di = (int)(item / tiles), tile = (int)(item - (long)di * tiles);
     int b = 0;
@@ -210,54 +207,58 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
     const half_t* pb = protos + (long)b * mh * mw * NM;
     for (int i = threadIdx.x; i < 18 * 18; i += 256) {
       const int ly = i / 18, lx = i - ly * 18;
-      const int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
+      // out-of-image halo cells replicate the border cell: identical to the reference's index clamping
+      // (src = max(src, 0); x1 = min(x0 + 1, W - 1)) but keeps the interpolation weights position-independent
+      int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
+      y = y < 0 ? 0 : (y >= mh ? mh - 1 : y);
+      x = x < 0 ? 0 : (x >= mw ? mw - 1 : x);
       float v = 0.f;
-      if (y >= 0 && y < mh && x >= 0 && x < mw) {
-        const float xf = (float)x, yf = (float)y;
-        if (xf >= bx1 && xf < bx2 && yf >= by1 && yf < by2) {
-          const half8* pp = (const half8*)(pb + ((long)y * mw + x) * NM);
-          float s = 0.f;
+      const float xf = (float)x, yf = (float)y;
+      if (xf >= bx1 && xf < bx2 && yf >= by1 && yf < by2) {
+        const half8* pp = (const half8*)(pb + ((long)y * mw + x) * NM);
+        float s = 0.f;
 #pragma unroll
-          for (int c8 = 0; c8 < NM / 8; ++c8) {
-            const half8 h = pp[c8];
+        for (int c8 = 0; c8 < NM / 8; ++c8) {
+          const half8 h = pp[c8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += coef[c8 * 8 + j] * (float)h[j];
-          }
-          v = s;
+          for (int j = 0; j < 8; ++j) s += coef[c8 * 8 + j] * (float)h[j];
         }
+        v = s;
       }
       lg[ly][lx] = v;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < out_h * segs; i += 256) {
-      const int oy = i / segs, seg = i - oy * segs;
-      const int Y = ty * out_h + oy;
-      if (Y >= in_h) continue;
-      float fy = sy * ((float)Y + 0.5f) - 0.5f;
-      if (fy < 0.f) fy = 0.f;
-      const int y0 = (int)fy;
-      const int y1 = y0 < mh - 1 ? y0 + 1 : y0;
-      const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
-      const int r0 = y0 - (ty * 16 - 1), r1 = y1 - (ty * 16 - 1);
-      uint8_t o[16];
+    // x4 bilinear, align_corners=False: output X = 4q + r reads cells (q-1, q) with weight of the right cell
+    // 0.625, 0.875 for r = 0, 1 and cells (q, q+1) with 0.125, 0.375 for r = 2, 3 (exact binary fractions).
+    // Thread = (output row oy, 16-pixel segment): 6 cells x 2 rows from LDS -> 16 pixels.
+    {
+      const int oy = threadIdx.x >> 2, seg = threadIdx.x & 3;
+      const int Y = ty * 64 + oy;
+      if (Y < in_h) {
+        const int qy = oy >> 2, ry = oy & 3;
+        const int r0 = (ry < 2) ? qy : qy + 1;  // tile-local halo row of the upper cell (cell -1 is row 0)
+        const float ly1 = (ry == 0) ? 0.625f : (ry == 1) ? 0.875f : (ry == 2) ? 0.125f : 0.375f;
+        const float ly0 = 1.f - ly1;
+        float cv[6];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const int X = tx * out_w + seg * 16 + j;
-        float fx = sx * ((float)X + 0.5f) - 0.5f;
-        if (fx < 0.f) fx = 0.f;
-        const int x0 = (int)fx;
-        const int x1 = x0 < mw - 1 ? x0 + 1 : x0;
-        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
-        const int c0 = x0 - (tx * 16 - 1), c1 = x1 - (tx * 16 - 1);
-        const float v = ly0 * (lx0 * lg[r0][c0] + lx1 * lg[r0][c1]) + ly1 * (lx0 * lg[r1][c0] + lx1 * lg[r1][c1]);
-        o[j] = v > 0.f ? 1 : 0;
-      }
-      const int X0 = tx * out_w + seg * 16;
-      uint8_t* mp = mbase + (long)Y * in_w + X0;
-      if (X0 + 16 <= in_w) {
-        *(uint4*)mp = *(const uint4*)o;
-      } else {
-        for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = o[j];
+        for (int c = 0; c < 6; ++c) cv[c] = ly0 * lg[r0][seg * 4 + c] + ly1 * lg[r0 + 1][seg * 4 + c];
+        uint8_t o[16];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          // cells (tile-local halo columns): left = seg*4 + q, mid = +1, right = +2
+          const float a0 = cv[q], a1 = cv[q + 1], a2 = cv[q + 2];
+          o[q * 4 + 0] = (0.375f * a0 + 0.625f * a1) > 0.f ? 1 : 0;
+          o[q * 4 + 1] = (0.125f * a0 + 0.875f * a1) > 0.f ? 1 : 0;
+          o[q * 4 + 2] = (0.875f * a1 + 0.125f * a2) > 0.f ? 1 : 0;
+          o[q * 4 + 3] = (0.625f * a1 + 0.375f * a2) > 0.f ? 1 : 0;
+        }
+        const int X0 = tx * 64 + seg * 16;
+        uint8_t* mp = mbase + (long)Y * in_w + X0;
+        if (X0 + 16 <= in_w) {
+          *(uint4*)mp = *(const uint4*)o;
+        } else {
+          for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = o[j];
+        }
       }
     }
   }

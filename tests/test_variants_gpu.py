@@ -1,0 +1,68 @@
+"""Parity of the HIP engine vs the CPU oracle across the configurations the reference / BASELINE.json name:
+n / s / m scales, nc = 1 and 80 (multi-class NMS), imgsz 320 (what yolo_seg_train.py:15 uses) and non-square
+inputs, batch sizes that do not fill a tile."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import build_oracle, synthetic_bscans
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+CASES = [
+    # scale, nc, (h, w), batch
+    ("n", 1, (640, 640), 3),
+    ("m", 1, (640, 640), 2),
+    ("s", 80, (320, 320), 5),
+    ("n", 3, (320, 480), 1),
+    ("s", 1, (320, 320), 7),
+]
+
+
+@pytest.mark.parametrize("scale,nc,shape,batch", CASES)
+def test_forward_and_postprocess_parity(scale, nc, shape, batch, cuda_device):
+    import yolov8_seg_oracle as orc
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict(scale, nc, seed=11, cls_bias=-2.5)
+    eng = SegEngine(scale, nc, shape, max_batch=batch)
+    eng.load_state_dict(sd)
+    oracle = build_oracle(scale, nc, sd)
+    imgs = synthetic_bscans(batch, shape[0], shape[1], seed=5)
+    x = torch.from_numpy(imgs.transpose(0, 3, 1, 2).copy()).float() / 255.0
+    with torch.no_grad():
+        o_preds, o_protos = oracle(x)
+    preds, protos = eng.forward(torch.from_numpy(imgs).to(cuda_device))
+    torch.cuda.synchronize()
+    A = o_preds.shape[2]
+    assert preds.shape == (batch, A, 4 + nc + 32)
+    e_pr = rel_l2(protos.float().cpu().permute(0, 3, 1, 2), o_protos)
+    gp, op = preds.cpu(), o_preds.permute(0, 2, 1)
+    e_box = float((gp[..., :4] - op[..., :4]).abs().median())
+    e_sc = float((gp[..., 4:4 + nc] - op[..., 4:4 + nc]).abs().max())
+    e_mc = rel_l2(gp[..., 4 + nc:], op[..., 4 + nc:])
+    print(f"{scale} nc={nc} {shape} b={batch}: proto {e_pr:.2e} coef {e_mc:.2e} box-median {e_box:.4f}px score-max {e_sc:.2e}")
+    assert e_pr <= 1e-2 and e_mc <= 1e-2 and e_box <= 0.5 and e_sc <= 2e-2
+    # NMS (+ multi-class offsets) bit-exact on identical preds; masks >= 99.5 %
+    for conf, iou, max_det in ((0.25, 0.7, 300), (0.05, 0.5, 20)):
+        dets, counts, masks = eng.postprocess(preds, protos, conf, iou, max_det)
+        torch.cuda.synchronize()
+        ref = orc.non_max_suppression(preds.cpu().permute(0, 2, 1).numpy(), nc, conf, iou, max_det)
+        tot = agree = 0
+        for b in range(batch):
+            n = int(counts[b])
+            assert n == ref[b].shape[0]
+            assert np.array_equal(dets[b, :n].cpu().numpy(), ref[b])
+            if n:
+                d = dets[b, :n].cpu()
+                m = orc.process_mask(protos[b].float().cpu().permute(2, 0, 1), d[:, 6:], d[:, :4], shape)
+                tot += m.numel()
+                agree += int((masks[b, :n].cpu().bool() == m).sum())
+        if tot:
+            assert agree / tot >= 0.995
+    eng.close()
