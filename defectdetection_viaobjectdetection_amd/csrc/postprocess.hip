@@ -149,111 +149,129 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Mask assembly (A12): for detection k of image b and one 16x16 tile of the prototype grid:
-//   logits(y,x) = sum_c coef[c] * proto[y][x][c]      on the tile + 1-pixel halo (18x18), in LDS
-//   zero outside the box scaled to the prototype grid (x1 <= col < x2, y1 <= row < y2)
-//   bilinear upsample x(in/mh) with align_corners=False  -> 64x64 output pixels, mask = value > 0
-// Persistent 256-thread blocks walk the work list (detection, tile) built from the device-side counts
-// (no host sync, no empty blocks); each thread emits 16 consecutive output pixels per 16-byte store.
-// Tiles that do not touch the (halo-extended) box are zero-filled without reading the prototypes.
-// NM prototypes (32) * fp16 = one 64-byte NHWC pixel.
+// Mask assembly (A12).  One 256-thread block per (image, 16x16 tile of the prototype grid):
+//   1. the 18x18x32 prototype patch (tile + 1-cell halo, border cells replicated = the reference's index
+//      clamping) is staged ONCE in LDS and shared by every detection of the image;
+//   2. detections are processed 16 at a time: logits[det][cell] = coef[det] . proto[cell] is one
+//      v_mfma_f32_16x16x32_f16 per 16 cells (coefficients split into fp16 hi + lo parts, two MFMAs, so the
+//      fp32 coefficients lose nothing); cells outside the detection's box (scaled to the prototype grid:
+//      x1 <= col < x2, y1 <= row < y2) are zeroed while the accumulators are written to LDS;
+//   3. x4 bilinear upsample (align_corners=False) + threshold > 0: output X = 4q + r reads cells (q-1, q)
+//      with right-cell weight 0.625 / 0.875 (r = 0, 1) and (q, q+1) with 0.125 / 0.375 (r = 2, 3); each
+//      thread turns 6 cells x 2 rows into 16 output pixels = one 16-byte store.
+// Detections whose box does not touch the tile's halo window get zero-filled without touching LDS.
 // ---------------------------------------------------------------------------------------------
+constexpr int MK_CELLS = 18 * 18;        // 324
+constexpr int MK_CELLS_PAD = 21 * 16;    // 336: whole 16-cell MFMA column blocks
+constexpr int MK_LG_PITCH = MK_CELLS_PAD + 4;
+
 template <int NM>
 __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, const int* counts, const half_t* protos,
-                                                          int B, int max_det, int mh, int mw, int in_h, int in_w,
+                                                          int max_det, int mh, int mw, int in_h, int in_w,
                                                           uint8_t* masks) {
-  __shared__ float lg[18][19];
-  __shared__ float coef[NM];
-  __shared__ int prefix[1025];  // prefix[b] = number of detections in images < b  (B <= 1024)
-  for (int i = threadIdx.x; i <= B; i += 256) {
-    int acc = 0;
-    for (int j = 0; j < i; ++j) acc += min(counts[j], max_det);
-    prefix[i] = acc;
-  }
-  __syncthreads();
-  const int tiles_x = (mw + 15) / 16, tiles_y = (mh + 15) / 16;
-  const int tiles = tiles_x * tiles_y;
-  const long total = (long)prefix[B] * tiles;
+  static_assert(NM == 32, "one 64-byte NHWC prototype pixel = one MFMA K step");
+  __shared__ __attribute__((aligned(16))) half_t patch[MK_CELLS_PAD * NM];   // 21.5 KB
+  __shared__ __attribute__((aligned(16))) float lg[16 * MK_LG_PITCH];        // 21.8 KB
+  __shared__ __attribute__((aligned(16))) half_t cf_hi[16 * NM], cf_lo[16 * NM];
+  __shared__ float bxs[16][4];
+  const int b = blockIdx.y;
+  int n = counts[b];
+  if (n > max_det) n = max_det;
+  if (n <= 0) return;
+  const int tiles_x = (mw + 15) / 16;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
   const float wr = (float)mw / (float)in_w, hr = (float)mh / (float)in_h;
-  constexpr int out_w = 64, out_h = 64, segs = 4;  // a 16x16 prototype tile covers 64 x 64 output pixels (x4)
-  for (long item = blockIdx.x; item < total; item += gridDim.x) {
-    const int di = (int)(item / tiles), tile = (int)(item - (long)di * tiles);
-    int b = 0;
-    while (prefix[b + 1] <= di) ++b;  // uniform per block
-    const int k = di - prefix[b];
-    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-    const float* d = dets + ((long)b * max_det + k) * (6 + NM);
-    const float bx1 = d[0] * wr, by1 = d[1] * hr, bx2 = d[2] * wr, by2 = d[3] * hr;
-    // does the tile's 18x18 halo window contain any in-box prototype pixel?
-    const float wx0 = (float)(tx * 16 - 1), wx1 = (float)(tx * 16 + 16), wy0 = (float)(ty * 16 - 1),
-                wy1 = (float)(ty * 16 + 16);
-    const bool touches = !(wx1 < bx1 || wx0 >= bx2 || wy1 < by1 || wy0 >= by2);
-    uint8_t* mbase = masks + ((long)b * max_det + k) * in_h * in_w;
-    if (!touches) {
-      const uint4 z = make_uint4(0, 0, 0, 0);
-      for (int i = threadIdx.x; i < out_h * segs; i += 256) {
-        const int oy = i / segs, seg = i - oy * segs;
-        const int Y = ty * out_h + oy, X0 = tx * out_w + seg * 16;
-        if (Y >= in_h) continue;
-        uint8_t* mp = mbase + (long)Y * in_w + X0;
-        if (X0 + 16 <= in_w) *(uint4*)mp = z;
-        else for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = 0;
-      }
-      continue;
-    }
-    __syncthreads();  // previous item's readers of lg/coef are done
-    if (threadIdx.x < NM) coef[threadIdx.x] = d[6 + threadIdx.x];
-    __syncthreads();
-    const half_t* pb = protos + (long)b * mh * mw * NM;
-    for (int i = threadIdx.x; i < 18 * 18; i += 256) {
-      const int ly = i / 18, lx = i - ly * 18;
-      // out-of-image halo cells replicate the border cell: identical to the reference's index clamping
-      // (src = max(src, 0); x1 = min(x0 + 1, W - 1)) but keeps the interpolation weights position-independent
+  // 1. prototype patch (4 x 16-byte chunks per cell)
+  const half_t* pb = protos + (long)b * mh * mw * NM;
+  for (int i = tid; i < MK_CELLS_PAD * 4; i += 256) {
+    const int cell = i >> 2, ch = i & 3;
+    half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (cell < MK_CELLS) {
+      const int ly = cell / 18, lx = cell - ly * 18;
       int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
       y = y < 0 ? 0 : (y >= mh ? mh - 1 : y);
       x = x < 0 ? 0 : (x >= mw ? mw - 1 : x);
+      v = *(const half8*)(pb + ((long)y * mw + x) * NM + ch * 8);
+    }
+    *(half8*)(patch + cell * NM + ch * 8) = v;
+  }
+  // halo window of this tile in prototype-grid coordinates (for the box-touch test)
+  const float wx0 = (float)(tx * 16 - 1), wx1 = (float)(tx * 16 + 16), wy0 = (float)(ty * 16 - 1),
+              wy1 = (float)(ty * 16 + 16);
+  const int oy = tid >> 2, seg = tid & 3;
+  const int Y = ty * 64 + oy, X0 = tx * 64 + seg * 16;
+  const int qy = oy >> 2, ry = oy & 3;
+  const int r0 = (ry < 2) ? qy : qy + 1;
+  const float ly1 = (ry == 0) ? 0.625f : (ry == 1) ? 0.875f : (ry == 2) ? 0.125f : 0.375f;
+  const float ly0 = 1.f - ly1;
+
+  for (int c0 = 0; c0 < n; c0 += 16) {
+    const int nd = (n - c0 < 16) ? (n - c0) : 16;
+    __syncthreads();  // previous chunk's readers of lg / cf / bxs are done (and the patch is complete)
+    // 2a. coefficients (hi + lo fp16) and scaled boxes of this chunk
+    for (int i = tid; i < 16 * NM; i += 256) {
+      const int d = i / NM, k = i - d * NM;
+      const float c = d < nd ? dets[((long)b * max_det + c0 + d) * (6 + NM) + 6 + k] : 0.f;
+      const half_t hi = (half_t)c;
+      cf_hi[i] = hi;
+      cf_lo[i] = (half_t)(c - (float)hi);
+    }
+    if (tid < 64) {
+      const int d = tid >> 2, f = tid & 3;
       float v = 0.f;
-      const float xf = (float)x, yf = (float)y;
-      if (xf >= bx1 && xf < bx2 && yf >= by1 && yf < by2) {
-        const half8* pp = (const half8*)(pb + ((long)y * mw + x) * NM);
-        float s = 0.f;
-#pragma unroll
-        for (int c8 = 0; c8 < NM / 8; ++c8) {
-          const half8 h = pp[c8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) s += coef[c8 * 8 + j] * (float)h[j];
-        }
-        v = s;
-      }
-      lg[ly][lx] = v;
+      if (d < nd) v = dets[((long)b * max_det + c0 + d) * (6 + NM) + f] * ((f & 1) ? hr : wr);
+      bxs[d][f] = v;
     }
     __syncthreads();
-    // x4 bilinear, align_corners=False: output X = 4q + r reads cells (q-1, q) with weight of the right cell
-    // 0.625, 0.875 for r = 0, 1 and cells (q, q+1) with 0.125, 0.375 for r = 2, 3 (exact binary fractions).
-    // Thread = (output row oy, 16-pixel segment): 6 cells x 2 rows from LDS -> 16 pixels.
+    // 2b. logits by MFMA: A = coefficients [16 dets][32], B = patch [32][16 cells]; D[det 4g+j][cell l15]
     {
-      const int oy = threadIdx.x >> 2, seg = threadIdx.x & 3;
-      const int Y = ty * 64 + oy;
-      if (Y < in_h) {
-        const int qy = oy >> 2, ry = oy & 3;
-        const int r0 = (ry < 2) ? qy : qy + 1;  // tile-local halo row of the upper cell (cell -1 is row 0)
-        const float ly1 = (ry == 0) ? 0.625f : (ry == 1) ? 0.875f : (ry == 2) ? 0.125f : 0.375f;
-        const float ly0 = 1.f - ly1;
-        float cv[6];
+      const half8 a_hi = *(const half8*)(cf_hi + l15 * NM + g * 8);
+      const half8 a_lo = *(const half8*)(cf_lo + l15 * NM + g * 8);
+      for (int t = wave; t < MK_CELLS_PAD / 16; t += 4) {
+        const int cell = t * 16 + l15;
+        const half8 bf = *(const half8*)(patch + cell * NM + g * 8);
+        float4v acc = {0.f, 0.f, 0.f, 0.f};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bf, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bf, acc, 0, 0, 0);
+        const int ly = cell / 18, lx = cell - ly * 18;
+        int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
+        y = y < 0 ? 0 : (y >= mh ? mh - 1 : y);
+        x = x < 0 ? 0 : (x >= mw ? mw - 1 : x);
+        const float xf = (float)x, yf = (float)y;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) cv[c] = ly0 * lg[r0][seg * 4 + c] + ly1 * lg[r0 + 1][seg * 4 + c];
-        uint8_t o[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          // cells (tile-local halo columns): left = seg*4 + q, mid = +1, right = +2
-          const float a0 = cv[q], a1 = cv[q + 1], a2 = cv[q + 2];
-          o[q * 4 + 0] = (0.375f * a0 + 0.625f * a1) > 0.f ? 1 : 0;
-          o[q * 4 + 1] = (0.125f * a0 + 0.875f * a1) > 0.f ? 1 : 0;
-          o[q * 4 + 2] = (0.875f * a1 + 0.125f * a2) > 0.f ? 1 : 0;
-          o[q * 4 + 3] = (0.625f * a1 + 0.375f * a2) > 0.f ? 1 : 0;
+        for (int j = 0; j < 4; ++j) {
+          const int d = g * 4 + j;
+          const bool in = xf >= bxs[d][0] && xf < bxs[d][2] && yf >= bxs[d][1] && yf < bxs[d][3];
+          lg[d * MK_LG_PITCH + cell] = in ? acc[j] : 0.f;
         }
-        const int X0 = tx * 64 + seg * 16;
-        uint8_t* mp = mbase + (long)Y * in_w + X0;
+      }
+    }
+    __syncthreads();
+    // 3. upsample + threshold + store, one detection after the other (no barrier in between)
+    if (Y < in_h) {
+      for (int d = 0; d < nd; ++d) {
+        const bool touches = !(wx1 < bxs[d][0] || wx0 >= bxs[d][2] || wy1 < bxs[d][1] || wy0 >= bxs[d][3]);
+        uint8_t o[16];
+        if (touches) {
+          const float* l0 = lg + d * MK_LG_PITCH + r0 * 18 + seg * 4;
+          float cv[6];
+#pragma unroll
+          for (int c = 0; c < 6; ++c) cv[c] = ly0 * l0[c] + ly1 * l0[18 + c];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float a0 = cv[q], a1 = cv[q + 1], a2 = cv[q + 2];
+            o[q * 4 + 0] = (0.375f * a0 + 0.625f * a1) > 0.f ? 1 : 0;
+            o[q * 4 + 1] = (0.125f * a0 + 0.875f * a1) > 0.f ? 1 : 0;
+            o[q * 4 + 2] = (0.875f * a1 + 0.125f * a2) > 0.f ? 1 : 0;
+            o[q * 4 + 3] = (0.625f * a1 + 0.375f * a2) > 0.f ? 1 : 0;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) o[j] = 0;
+        }
+        uint8_t* mp = masks + (((long)b * max_det + c0 + d) * in_h + Y) * in_w + X0;
         if (X0 + 16 <= in_w) {
           *(uint4*)mp = *(const uint4*)o;
         } else {
@@ -297,8 +315,8 @@ int launch_proto_masks(const float* dets, const int* counts, const half_t* proto
                        int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s) {
   if (nm != 32) return -1;
   if (in_h % mh || in_w % mw || in_w / mw != 4 || in_h / mh != 4 || in_w % 16) return -1;
-  if (B > 1024) return -1;
-  hipLaunchKernelGGL(proto_masks_kernel<32>, dim3(256 * 8), dim3(256), 0, s, dets, counts, protos, B, max_det, mh, mw,
+  const int tiles = ((mw + 15) / 16) * ((mh + 15) / 16);
+  hipLaunchKernelGGL(proto_masks_kernel<32>, dim3(tiles, B), dim3(256), 0, s, dets, counts, protos, max_det, mh, mw,
                      in_h, in_w, masks);
   return (int)hipGetLastError();
 }
