@@ -427,6 +427,7 @@ void annotate_ops(m355_engine* e) {
           op.flops = 2.0 * Ho * Wo * p.cout * p.cin * p.k * p.k;
         }
         op.tile = conv_pick_tile(cout_v, e->desc.max_batch * Ho * Wo);
+        if (k == 1 && op.tile == TILE_128x128 && getenv("M355_K1_TILE")) op.tile = atoi(getenv("M355_K1_TILE"));
         {
           ConvArgs probe{};
           probe.ksize = p.k; probe.stride = p.stride; probe.pad = p.k / 2; probe.out_f32 = (op.out_ext == 1);
