@@ -36,6 +36,7 @@ struct ConvArgs {
   int out_f32;         // 1: store fp32
   int convt_co;        // >0: ConvTranspose 2x2/s2 pixel-shuffle store with Co = convt_co
   const half_t* zero;  // >=16 bytes of zeros in device memory (source for padded taps)
+  int tmode;           // 1: transposed-stride gather = dgrad of a 3x3 / stride-2 / pad-1 conv (x is dY, y is dX)
   int dbg;             // ablation switches for profiling experiments (0 in production)
   unsigned long long* stamps;  // diagnostic builds: per-block s_memtime stamps (nullptr in production)
 };
@@ -73,5 +74,13 @@ int launch_nms(const float* preds, int B, int A, int nc, int nm, float conf, flo
 size_t nms_workspace_bytes(int B, int A);
 int launch_proto_masks(const float* dets, const int* counts, const half_t* protos, int B, int max_det,
                        int nm, int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s);
+
+// train-mode BatchNorm + SiLU (train_kernels.hip)
+int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
+                             float eps, half_t* y, int ldy, float* sums, float* mean_out, float* invstd_out, int act,
+                             hipStream_t s);
+int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int ldz, int lddy, int C, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, float* rsum, half_t* dz,
+                             int lddz, int act, hipStream_t s);
 
 }  // namespace m355

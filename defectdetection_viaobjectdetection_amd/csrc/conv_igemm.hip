@@ -115,10 +115,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       int b, pix, ho, wo;
       fast_divmod(mm, HoWo, inv_howo, b, pix);
       fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+      unsigned mk = 0;
+      if (KS == 3 && a.tmode) {
+        // dgrad of a stride-2 conv: output pixel (ho, wo) is the forward INPUT pixel; tap (kh, kw) reads
+        // dY[(ho + 1 - kh) / 2][(wo + 1 - kw) / 2] when the parities match.  For valid taps
+        // (ho + 1 - kh) / 2 == ((ho + 1) >> 1) - (kh >> 1), so the address stays base + per-tap offset.
+        const int hb = (ho + 1) >> 1, wb = (wo + 1) >> 1;
+        rowoff[i] = (long)b * a.x_bstride + ((long)hb * a.Wi + wb) * a.ldx;
+        const unsigned ph = (unsigned)(ho + 1) & 1u, pw = (unsigned)(wo + 1) & 1u;
+        unsigned rv = 0, cv = 0;
+        if (ph) {
+          rv = ((unsigned)hb < (unsigned)a.Hi) ? 2u : 0u;                       // kh = 1
+        } else {
+          rv = (((unsigned)hb < (unsigned)a.Hi) ? 1u : 0u) | (((unsigned)(hb - 1) < (unsigned)a.Hi) ? 4u : 0u);  // kh = 0, 2
+        }
+        if (pw) {
+          cv = ((unsigned)wb < (unsigned)a.Wi) ? 2u : 0u;
+        } else {
+          cv = (((unsigned)wb < (unsigned)a.Wi) ? 1u : 0u) | (((unsigned)(wb - 1) < (unsigned)a.Wi) ? 4u : 0u);
+        }
+        mk = ((rv & 1u) ? cv : 0u) | ((rv & 2u) ? (cv << 3) : 0u) | ((rv & 4u) ? (cv << 6) : 0u);
+        if (!mv) mk = 0;
+        rowmask[i] = mk;
+        continue;
+      }
       const int hi0 = ho * a.stride - a.pad;
       const int wi0 = wo * a.stride - a.pad;
       rowoff[i] = (long)b * a.x_bstride + ((long)hi0 * a.Wi + wi0) * a.ldx;
-      unsigned mk = 0;
       if (KS == 1) {
         mk = mv ? 1u : 0u;
       } else {
@@ -170,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       cin = kq - tap * a.Cin;
       const int kh = (tap * 11) >> 5;  // tap/3 for tap < 12
       const int kw = tap - kh * 3;
-      tapoff = (kh * a.Wi + kw) * a.ldx + cin;
+      tapoff = a.tmode ? (cin - ((kh >> 1) * a.Wi + (kw >> 1)) * a.ldx) : ((kh * a.Wi + kw) * a.ldx + cin);
     }
     char* ab = sb + BCH * ROWB;
 #pragma unroll

@@ -848,6 +848,73 @@ int m355_conv2d_fwd(const void* d_x, int B, int H, int W, int cin, const float* 
                         stream);
 }
 
+int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const float* h_w, int cout, int k, int stride,
+                      void* d_dx, void* stream) {
+  if (!d_dy || !h_w || !d_dx) return set_err(M355_ERR_INVALID, "null pointer");
+  if ((k != 1 && k != 3) || (stride != 1 && stride != 2) || (k == 1 && stride != 1))
+    return set_err(M355_ERR_INVALID, "dgrad supports k=3 (stride 1, 2) and k=1 (stride 1)");
+  if (cin % 8 || cout % 8) return set_err(M355_ERR_INVALID, "channels must be multiples of 8");
+  hipStream_t s = (hipStream_t)stream;
+  const int pad = k / 2;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  // dgrad as a conv with "output channels" = cin and K = (tap, cout): row ci, column (tap', co)
+  //   stride 1: tap' = flipped tap (kh' = k-1-kh);  stride 2 (transposed-stride gather): tap' = tap
+  const int cout_pad = conv_cout_pad(cin);
+  const int Kpad = conv_kpad(cout, k);
+  std::vector<half_t> rows((size_t)cout_pad * Kpad, (half_t)0.f);
+  for (int co = 0; co < cout; ++co)
+    for (int ci = 0; ci < cin; ++ci)
+      for (int kh = 0; kh < k; ++kh)
+        for (int kw = 0; kw < k; ++kw) {
+          const int t = (stride == 1) ? ((k - 1 - kh) * k + (k - 1 - kw)) : (kh * k + kw);
+          rows[(size_t)ci * Kpad + (size_t)t * cout + co] = (half_t)h_w[(((size_t)co * cin + ci) * k + kh) * k + kw];
+        }
+  std::vector<float> bias(cout_pad, 0.f);
+  half_t *dw = nullptr, *dz = nullptr;
+  float* db = nullptr;
+  HIP_TRYG(hipMalloc((void**)&dw, rows.size() * sizeof(half_t)));
+  HIP_TRYG(hipMalloc((void**)&db, bias.size() * sizeof(float)));
+  HIP_TRYG(hipMalloc((void**)&dz, 256));
+  HIP_TRYG(hipMemset(dz, 0, 256));
+  HIP_TRYG(hipMemcpy(dw, rows.data(), rows.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  ConvArgs a{};
+  a.x = (const half_t*)d_dy; a.x_bstride = (long)Ho * Wo * cout; a.ldx = cout; a.Hi = Ho; a.Wi = Wo; a.Cin = cout;
+  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = 0;
+  a.y = d_dx; a.y_bstride = (long)H * W * cin; a.ldy = cin; a.Ho = H; a.Wo = W; a.Cout = cin;
+  a.ksize = k; a.stride = 1; a.pad = pad; a.tmode = (stride == 2) ? 1 : 0;
+  a.M = B * H * W;
+  int rc;
+  if (!a.tmode && conv3x3_halo_ok(a))
+    rc = launch_conv3x3_halo(a, 0, s);
+  else
+    rc = launch_conv_igemm(a, TILE_AUTO, s);
+  hipError_t se = hipStreamSynchronize(s);
+  (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dz);
+  if (rc != 0) return set_err(M355_ERR_HIP, "dgrad launch failed: " + std::to_string(rc));
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("dgrad kernel: ") + hipGetErrorString(se));
+  return M355_OK;
+}
+
+int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const float* d_gamma, const float* d_beta,
+                           float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream) {
+  if (!d_z || !d_gamma || !d_beta || !d_y || !d_mean || !d_invstd || !d_ws) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_bn_silu_train_fwd((const half_t*)d_z, (long)B * H * W, C, C, d_gamma, d_beta, eps, (half_t*)d_y, C,
+                                          d_ws, d_mean, d_invstd, act, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn fwd launch failed: " + std::to_string(rc));
+}
+
+int m355_bn_silu_train_bwd(const void* d_z, const void* d_dy, int B, int H, int W, int C, const float* d_mean,
+                           const float* d_invstd, const float* d_gamma, const float* d_beta, int act, void* d_dz,
+                           float* d_dbeta_dgamma, void* stream) {
+  if (!d_z || !d_dy || !d_mean || !d_invstd || !d_gamma || !d_beta || !d_dz || !d_dbeta_dgamma)
+    return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_bn_silu_train_bwd((const half_t*)d_z, (const half_t*)d_dy, (long)B * H * W, C, C, C, d_mean,
+                                          d_invstd, d_gamma, d_beta, d_dbeta_dgamma, (half_t*)d_dz, C, act,
+                                          (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn bwd launch failed: " + std::to_string(rc));
+}
+
 int m355_convt2x2_fwd(const void* d_x, int B, int H, int W, int cin, const float* h_w, const float* h_bias, int cout,
                       void* d_y, void* stream) {
   return conv_op_common(d_x, B, H, W, cin, h_w, h_bias, cout, 2, 2, 0, nullptr, d_y, 0, TILE_AUTO, 1, stream);

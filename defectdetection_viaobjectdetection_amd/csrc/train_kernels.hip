@@ -1,0 +1,201 @@
+// Train-mode building blocks: BatchNorm2d with batch statistics + SiLU, forward and backward,
+// on NHWC fp16 activations with fp32 statistics.  Replaces aten batch_norm / silu (+ their autograd) reached
+// from SegmentationModel.forward in training mode (call site BscanBased/yolo_seg_train.py:12).
+// All HBM-bound: one 16-byte chunk (8 channels) per lane, per-channel fp32 partial sums in registers,
+// block reduction through LDS, one float atomic per (block, channel).
+#include "common.h"
+
+namespace m355 {
+namespace {
+
+constexpr int BN_THREADS = 256;
+
+__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// sums[0:C] += sum_px z, sums[C:2C] += sum_px z^2
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const half_t* z, long npix, int ld, int C, float* sums) {
+  extern __shared__ float red[];  // [BN_THREADS][16]
+  const int cg = C / 8;                       // channel groups
+  const int lanes_px = BN_THREADS / cg;       // pixel lanes per block (threads beyond lanes_px * cg idle)
+  const int cgi = threadIdx.x % cg, pl = threadIdx.x / cg;
+  float s[8], q[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = q[j] = 0.f;
+  if (pl < lanes_px) {
+    for (long p = (long)blockIdx.x * lanes_px + pl; p < npix; p += (long)gridDim.x * lanes_px) {
+      const half8 v = *(const half8*)(z + p * ld + cgi * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        s[j] += f;
+        q[j] += f * f;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[threadIdx.x * 16 + j] = s[j];
+    red[threadIdx.x * 16 + 8 + j] = q[j];
+  }
+  __syncthreads();
+  // thread t < 2*C: channel c = t % C, kind = t / C
+  for (int t = threadIdx.x; t < 2 * C; t += BN_THREADS) {
+    const int kind = t / C, c = t - kind * C;
+    const int g = c / 8, j = c - g * 8;
+    float acc = 0.f;
+    for (int l = 0; l < lanes_px; ++l) acc += red[(l * cg + g) * 16 + kind * 8 + j];
+    atomicAdd(&sums[t], acc);
+  }
+}
+
+// mean / invstd from the sums (biased variance, like torch batch_norm in training mode), optional
+// running-stat update with momentum (unbiased variance), then y = silu(gamma * (z - mean) * invstd + beta)
+__global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t* z, long npix, int ldz, int C,
+                                                                   const float* sums, const float* gamma,
+                                                                   const float* beta, float eps, half_t* y, int ldy,
+                                                                   float* mean_out, float* invstd_out, int act) {
+  const int cg = C / 8;
+  const long total = npix * cg;
+  const float inv_n = 1.0f / (float)npix;
+  for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * BN_THREADS) {
+    const long p = i / cg;
+    const int g = (int)(i - p * cg);
+    const half8 v = *(const half8*)(z + p * ldz + g * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g * 8 + j;
+      const float m = sums[c] * inv_n;
+      const float var = fmaxf(sums[C + c] * inv_n - m * m, 0.f);
+      const float is = rsqrtf(var + eps);
+      const float u = gamma[c] * ((float)v[j] - m) * is + beta[c];
+      o[j] = (half_t)(act ? u * sigmoid_f(u) : u);
+      if (p == 0 && mean_out) {
+        mean_out[c] = m;
+        invstd_out[c] = is;
+      }
+    }
+    *(half8*)(y + p * ldy + g * 8) = o;
+  }
+}
+
+// backward reductions: rsum[0:C] += sum du, rsum[C:2C] += sum du * xhat, du = dy * silu'(u)
+__global__ __launch_bounds__(BN_THREADS) void bn_silu_bwd_reduce_kernel(const half_t* z, const half_t* dy, long npix,
+                                                                        int ldz, int lddy, int C, const float* mean,
+                                                                        const float* invstd, const float* gamma,
+                                                                        const float* beta, float* rsum, int act) {
+  extern __shared__ float red[];
+  const int cg = C / 8;
+  const int lanes_px = BN_THREADS / cg;
+  const int cgi = threadIdx.x % cg, pl = threadIdx.x / cg;
+  float s[8], q[8], m[8], is[8], ga[8], be[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = q[j] = 0.f;
+    const int c = cgi * 8 + j;
+    m[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+  }
+  if (pl < lanes_px) {
+    for (long p = (long)blockIdx.x * lanes_px + pl; p < npix; p += (long)gridDim.x * lanes_px) {
+      const half8 v = *(const half8*)(z + p * ldz + cgi * 8);
+      const half8 d = *(const half8*)(dy + p * lddy + cgi * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = ((float)v[j] - m[j]) * is[j];
+        float du = (float)d[j];
+        if (act) {
+          const float u = ga[j] * xh + be[j];
+          const float sg = sigmoid_f(u);
+          du *= sg * (1.0f + u * (1.0f - sg));
+        }
+        s[j] += du;
+        q[j] += du * xh;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    red[threadIdx.x * 16 + j] = s[j];
+    red[threadIdx.x * 16 + 8 + j] = q[j];
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * C; t += BN_THREADS) {
+    const int kind = t / C, c = t - kind * C;
+    const int g = c / 8, j = c - g * 8;
+    float acc = 0.f;
+    for (int l = 0; l < lanes_px; ++l) acc += red[(l * cg + g) * 16 + kind * 8 + j];
+    atomicAdd(&rsum[t], acc);
+  }
+}
+
+// dz = gamma * invstd * (du - dbeta / N - xhat * dgamma / N)
+__global__ __launch_bounds__(BN_THREADS) void bn_silu_bwd_apply_kernel(const half_t* z, const half_t* dy, long npix,
+                                                                       int ldz, int lddy, int C, const float* mean,
+                                                                       const float* invstd, const float* gamma,
+                                                                       const float* beta, const float* rsum,
+                                                                       half_t* dz, int lddz, int act) {
+  const int cg = C / 8;
+  const long total = npix * cg;
+  const float inv_n = 1.0f / (float)npix;
+  for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * BN_THREADS) {
+    const long p = i / cg;
+    const int g = (int)(i - p * cg);
+    const half8 v = *(const half8*)(z + p * ldz + g * 8);
+    const half8 d = *(const half8*)(dy + p * lddy + g * 8);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = g * 8 + j;
+      const float xh = ((float)v[j] - mean[c]) * invstd[c];
+      float du = (float)d[j];
+      if (act) {
+        const float u = gamma[c] * xh + beta[c];
+        const float sg = sigmoid_f(u);
+        du *= sg * (1.0f + u * (1.0f - sg));
+      }
+      o[j] = (half_t)(gamma[c] * invstd[c] * (du - rsum[c] * inv_n - xh * rsum[C + c] * inv_n));
+    }
+    *(half8*)(dz + p * lddz + g * 8) = o;
+  }
+}
+
+int grid_for(long work_items) {
+  long b = (work_items + BN_THREADS - 1) / BN_THREADS;
+  if (b > 256 * 8) b = 256 * 8;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+// sums: device float[2C] zeroed by this call (hipMemsetAsync on the same stream)
+int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
+                             float eps, half_t* y, int ldy, float* sums, float* mean_out, float* invstd_out, int act,
+                             hipStream_t s) {
+  if (C % 8 || ldz % 8 || ldy % 8 || C / 8 > BN_THREADS) return -1;
+  hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  const int lanes_px = BN_THREADS / (C / 8);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
+                     BN_THREADS * 16 * sizeof(float), s, z, npix, ldz, C, sums);
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(BN_THREADS), 0, s, z, npix, ldz, C, sums,
+                     gamma, beta, eps, y, ldy, mean_out, invstd_out, act);
+  return (int)hipGetLastError();
+}
+
+// rsum: device float[2C] (zeroed here); on return rsum[0:C] = dbeta, rsum[C:2C] = dgamma
+int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int ldz, int lddy, int C, const float* mean,
+                             const float* invstd, const float* gamma, const float* beta, float* rsum, half_t* dz,
+                             int lddz, int act, hipStream_t s) {
+  if (C % 8 || ldz % 8 || lddy % 8 || lddz % 8 || C / 8 > BN_THREADS) return -1;
+  hipError_t e = hipMemsetAsync(rsum, 0, 2 * C * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  const int lanes_px = BN_THREADS / (C / 8);
+  hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid_for(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
+                     BN_THREADS * 16 * sizeof(float), s, z, dy, npix, ldz, lddy, C, mean, invstd, gamma, beta, rsum, act);
+  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
+                     lddy, C, mean, invstd, gamma, beta, rsum, dz, lddz, act);
+  return (int)hipGetLastError();
+}
+
+}  // namespace m355

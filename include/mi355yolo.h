@@ -128,6 +128,21 @@ int m355_conv2d_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, cons
                     const float* h_bias, int cout, int k, int stride, int act,
                     const void* d_res_f16_nhwc, void* d_y_f16_nhwc, int out_f32, int force_tile,
                     void* stream);
+/* Data gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2, no bias) (SURVEY A13 backward): dY fp16 NHWC
+ * (B,Ho,Wo,cout) -> dX fp16 NHWC (B,H,W,cin).  Runs on the same implicit-GEMM kernel: stride 1 = convolution
+ * with the spatially flipped, channel-transposed weights; stride 2 = transposed-stride gather.  h_w is the
+ * FORWARD weight fp32 (cout,cin,k,k) on the host.                                                   [sync] */
+int m355_conv2d_dgrad(const void* d_dy_f16_nhwc, int B, int H, int W, int cin, const float* h_w, int cout, int k,
+                      int stride, void* d_dx_f16_nhwc, void* stream);
+/* Train-mode BatchNorm2d (batch statistics, biased variance, eps) + optional SiLU on fp16 NHWC (B,H,W,C)
+ * (SURVEY A13): y = act(gamma * (z - mean) * invstd + beta).  gamma/beta/mean/invstd/ws are DEVICE fp32 arrays;
+ * d_ws is a 2*C float workspace (sum, sum of squares); d_mean/d_invstd receive the saved statistics. */
+int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const float* d_gamma, const float* d_beta,
+                           float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream);
+/* Backward of the above: dz (fp16 NHWC) and d_dbeta_dgamma (device float[2*C]: [0:C] = dbeta, [C:2C] = dgamma). */
+int m355_bn_silu_train_bwd(const void* d_z, const void* d_dy, int B, int H, int W, int C, const float* d_mean,
+                           const float* d_invstd, const float* d_gamma, const float* d_beta, int act, void* d_dz,
+                           float* d_dbeta_dgamma, void* stream);
 /* ConvTranspose2d(k=2,s=2)+bias; h_w fp32 (cin,cout,2,2).                                   [sync] */
 int m355_convt2x2_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, const float* h_w,
                       const float* h_bias, int cout, void* d_y_f16_nhwc, void* stream);

@@ -1,0 +1,87 @@
+"""Backward building blocks (SURVEY A13 backward) vs PyTorch autograd on the CPU (fp32 on fp16-rounded operands)."""
+import ctypes as C
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def nhwc16(x_nchw, dev):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(torch.float16).to(dev)
+
+
+def rel_l2(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+DGRAD_CASES = [
+    # B, H, W, cin, cout, k, stride
+    (2, 16, 16, 64, 64, 3, 1),       # halo path
+    (2, 20, 24, 32, 64, 3, 1),       # im2col path (Cin of the dgrad GEMM = cout = 64, output channels 32)
+    (2, 16, 16, 128, 64, 1, 1),
+    (2, 32, 32, 64, 128, 3, 2),      # transposed-stride gather
+    (1, 34, 22, 32, 64, 3, 2),       # odd output sizes (17 x 11)
+    (3, 40, 40, 128, 256, 3, 2),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv2d_dgrad(case, cuda_device):
+    from defectdetection_viaobjectdetection_amd import _capi
+    B, H, W, cin, cout, k, s = case
+    g = torch.Generator().manual_seed(sum(case))
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).half().float()
+    x = torch.randn(B, cin, H, W, generator=g, requires_grad=True)
+    y = F.conv2d(x, w, None, stride=s, padding=k // 2)
+    dy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(dy)
+    d_dy = nhwc16(dy, cuda_device)
+    d_dx = torch.full((B, H, W, cin), float("nan"), dtype=torch.float16, device=cuda_device)
+    _capi.check(_capi.lib.m355_conv2d_dgrad(_p(d_dy), B, H, W, cin, _p(w.contiguous()), cout, k, s, _p(d_dx),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    got = d_dx.float().cpu().permute(0, 3, 1, 2)
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, x.grad) <= 1e-3
+
+
+@pytest.mark.parametrize("shape,act", [((4, 20, 20, 64), 1), ((2, 40, 24, 128), 1), ((3, 16, 16, 48), 1), ((2, 8, 8, 512), 0)])
+def test_bn_silu_train_fwd_bwd(shape, act, cuda_device):
+    """Train-mode BatchNorm(+SiLU) forward and backward vs torch (batch statistics, eps 1e-3)."""
+    from defectdetection_viaobjectdetection_amd import _capi
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(Cc + H)
+    z = (torch.randn(B, Cc, H, W, generator=g) * 1.7 + 0.3).half().float().requires_grad_(True)
+    gamma = (0.8 + 0.4 * torch.rand(Cc, generator=g)).requires_grad_(True)
+    beta = (0.2 * torch.rand(Cc, generator=g) - 0.1).requires_grad_(True)
+    u = F.batch_norm(z, None, None, gamma, beta, True, 0.0, 1e-3)
+    y = F.silu(u) if act else u
+    dy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(dy)
+    dev = cuda_device
+    d_z, d_dy = nhwc16(z.detach(), dev), nhwc16(dy, dev)
+    d_g, d_b = gamma.detach().to(dev), beta.detach().to(dev)
+    d_y = torch.empty((B, H, W, Cc), dtype=torch.float16, device=dev)
+    d_mean = torch.empty(Cc, device=dev)
+    d_is = torch.empty(Cc, device=dev)
+    d_ws = torch.empty(2 * Cc, device=dev)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _capi.check(_capi.lib.m355_bn_silu_train_fwd(_p(d_z), B, H, W, Cc, _p(d_g), _p(d_b), 1e-3, act, _p(d_y), _p(d_mean),
+                                                 _p(d_is), _p(d_ws), st))
+    d_dz = torch.empty_like(d_y)
+    d_gb = torch.empty(2 * Cc, device=dev)
+    _capi.check(_capi.lib.m355_bn_silu_train_bwd(_p(d_z), _p(d_dy), B, H, W, Cc, _p(d_mean), _p(d_is), _p(d_g), _p(d_b), act,
+                                                 _p(d_dz), _p(d_gb), st))
+    torch.cuda.synchronize()
+    zd = z.detach()
+    assert torch.allclose(d_mean.cpu(), zd.mean((0, 2, 3)), atol=1e-4)
+    assert torch.allclose(d_is.cpu(), 1 / torch.sqrt(zd.var((0, 2, 3), unbiased=False) + 1e-3), rtol=1e-4)
+    assert rel_l2(d_y.float().cpu().permute(0, 3, 1, 2), y.detach()) <= 1e-3
+    assert rel_l2(d_dz.float().cpu().permute(0, 3, 1, 2), z.grad) <= 2e-3
+    assert rel_l2(d_gb[:Cc].cpu(), beta.grad) <= 1e-3
+    assert rel_l2(d_gb[Cc:].cpu(), gamma.grad) <= 1e-3
