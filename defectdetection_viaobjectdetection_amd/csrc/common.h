@@ -75,6 +75,11 @@ size_t nms_workspace_bytes(int B, int A);
 int launch_proto_masks(const float* dets, const int* counts, const half_t* protos, int B, int max_det,
                        int nm, int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s);
 
+// weight gradient (conv_wgrad.hip): dw fp32 [Cout][k*k*Cin] (KRSC), zeroed + accumulated by the call
+int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
+                      int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, float* dw,
+                      const half_t* zero, hipStream_t s);
+
 // train-mode BatchNorm + SiLU (train_kernels.hip)
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
                              float eps, half_t* y, int ldy, float* sums, float* mean_out, float* invstd_out, int act,

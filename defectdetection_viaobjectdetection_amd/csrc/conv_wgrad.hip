@@ -1,0 +1,214 @@
+// Weight gradient of an NHWC fp16 convolution on CDNA4 MFMA (gfx950), fp32 accumulate / fp32 output.
+// Replaces the wgrad half of aten conv2d's autograd reached from SegmentationTrainer's backward
+// (call site BscanBased/yolo_seg_train.py:12).
+//
+//   dW[co][n] = sum_px dZ[px][co] * Xcol[px][n],      n = (kh*KS + kw)*Cin + ci      (KRSC layout, = the
+//   packed forward-weight order), px = (b, ho, wo), Xcol[px][n] = X[b, ho*s - p + kh, wo*s - p + kw, ci].
+//
+// A GEMM whose reduction dimension is the PIXEL axis: both operands are row = pixel images in memory (NHWC),
+// i.e. K-major the "wrong" way for MFMA fragments (a lane needs 8 consecutive pixels of ONE channel).  They
+// are staged as they lie -- 64 pixel rows x 128 channels (256 B rows) by LDS-DMA with a per-lane gathered
+// source address, zero page for padding / out-of-range -- and read back with gfx950's transposed LDS read
+// ds_read_b64_tr_b16 (4 rows x 16 columns -> column-major, two reads = the 8 k-values of a fragment).  The
+// 16-byte chunk index of a row is XOR-swizzled with f(row) = 2*(row&3) | ((row>>3)&1)<<3 (source side + read
+// side), found by exhaustive search: every transposed read is bank-conflict free.
+// Block = 128 co x 128 n output tile, 4 waves (64 x 64 each, 16 accumulator tiles), K step = 64 pixels, two
+// LDS stages; the pixel axis is split across blocks (split-K) and partial tiles are added with float atomics
+// (shape: 16 consecutive fp32 per row segment; the dW tensor is tiny next to the activations).
+#include "common.h"
+
+namespace m355 {
+
+struct WgradArgs {
+  const half_t* dz; long dz_bstride; int lddz;  // dZ (B,Ho,Wo,Cout) slice
+  const half_t* x;  long x_bstride;  int ldx;   // X  (B,Hi,Wi,Cin) slice
+  int Hi, Wi, Cin, Ho, Wo, Cout;
+  int ksize, stride, pad;
+  int M;        // B*Ho*Wo
+  int N;        // ksize*ksize*Cin
+  float* dw;    // [Cout][N] fp32, pre-zeroed, accumulated atomically
+  int splitk, steps_per_split;
+  const half_t* zero;
+};
+
+namespace {
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, int& r) {
+  q = (int)((float)n * inv_d);
+  r = n - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
+
+__device__ __forceinline__ half8 tr_frag(const char* p) {
+  // two transposed reads: rows +0..3 and +4..7 (4 rows = 1024 bytes apart) -> 8 k-values of one column
+  const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)p);
+  const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) short4v*)(p + 1024));
+  half8 r;
+  const half4 l4 = *(const half4*)&lo, h4 = *(const half4*)&hi;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { r[j] = l4[j]; r[4 + j] = h4[j]; }
+  return r;
+}
+
+constexpr int KST = 64;            // pixels per K step
+constexpr int ROWB2 = 256;         // LDS row = 128 channels
+constexpr int OPB = KST * ROWB2;   // bytes per operand per stage (16 KB)
+constexpr int STAGE2 = 2 * OPB;
+
+template <int KS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int co_tiles = (a.Cout + 127) / 128, n_tiles = (a.N + 127) / 128;
+  int bid = blockIdx.x;
+  const int split = bid / (co_tiles * n_tiles);
+  bid -= split * co_tiles * n_tiles;
+  const int n_tile = bid / co_tiles, co_tile = bid - n_tile * co_tiles;
+  const int co_base = co_tile * 128, n_base = n_tile * 128;
+  const int steps_total = (a.M + KST - 1) / KST;
+  const int step0 = split * a.steps_per_split;
+  int nsteps = steps_total - step0;
+  if (nsteps > a.steps_per_split) nsteps = a.steps_per_split;
+  if (nsteps <= 0) return;
+
+  // ---- loader: instr i of this wave fills rows R = 16*wave + 4*i + (lane>>4), slot = lane & 15;
+  // source chunk = slot ^ f(R), f(R) = 2*(R&3) | ((R>>3)&1)<<3 = 2*(lane>>4) | ((i>>1)&1)<<3
+  const int lr = lane >> 4, slot = lane & 15;
+  const int c_lo = slot ^ (2 * lr), c_hi = c_lo ^ 8;
+  const int HoWo = a.Ho * a.Wo;
+  const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)a.Wo;
+  // per chunk-variant: A channel offset and B (tap, ci)
+  int a_off[2], b_kh[2], b_kw[2], b_ci[2];
+  bool a_ok[2], b_ok[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int c = v ? c_hi : c_lo;
+    a_off[v] = co_base + c * 8;
+    a_ok[v] = a_off[v] < a.Cout;
+    const int n = n_base + c * 8;
+    b_ok[v] = n < a.N;
+    const int tap = n / a.Cin;
+    b_ci[v] = n - tap * a.Cin;
+    b_kh[v] = tap / KS;
+    b_kw[v] = tap - b_kh[v] * KS;
+  }
+  auto stage = [&](int t, int buf) {
+    char* sa = smem + buf * STAGE2;
+    char* sb = sa + OPB;
+    const int k0 = (step0 + t) * KST;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int v = i >> 1;
+      const int m = k0 + 16 * wave + 4 * i + lr;
+      const bool mv = m < a.M;
+      int b, pix, ho, wo;
+      fast_divmod(mv ? m : 0, HoWo, inv_howo, b, pix);
+      fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+      const half_t* srcA = (mv && a_ok[v]) ? (a.dz + (long)b * a.dz_bstride + (long)pix * a.lddz + a_off[v]) : a.zero;
+      const int hi = ho * a.stride - a.pad + b_kh[v], wi = wo * a.stride - a.pad + b_kw[v];
+      const bool okb = mv && b_ok[v] && (unsigned)hi < (unsigned)a.Hi && (unsigned)wi < (unsigned)a.Wi;
+      const half_t* srcB = okb ? (a.x + (long)b * a.x_bstride + ((long)hi * a.Wi + wi) * a.ldx + b_ci[v]) : a.zero;
+      glds16(srcA, sa + (16 * wave + 4 * i) * ROWB2);
+      glds16(srcB, sb + (16 * wave + 4 * i) * ROWB2);
+    }
+  };
+
+  // ---- fragment addresses: lane = (k-group G = lane>>4, li = lane&15 -> q = li>>2, p = li&3)
+  const int wm = wave >> 1, wn = wave & 1;
+  const int G = lane >> 4, li = lane & 15, q = li >> 2, p = li & 3;
+  const int frow = 8 * G + q;                             // + 4 for the second read, + 32 for ks = 1
+  const int fsw = (2 * q) | ((G & 1) << 3);               // f(row) for every row this lane addresses
+  int aoff[4], boff[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int chA = (wm * 64 + t * 16 + 4 * p) >> 3, chB = (wn * 64 + t * 16 + 4 * p) >> 3;
+    aoff[t] = frow * ROWB2 + ((chA ^ fsw) << 4) + (p & 1) * 8;
+    boff[t] = OPB + frow * ROWB2 + ((chB ^ fsw) << 4) + (p & 1) * 8;
+  }
+
+  float4v acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+
+  stage(0, 0);
+  for (int t = 0; t < nsteps; ++t) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t + 1 < nsteps) stage(t + 1, (t + 1) & 1);
+    const char* sb = smem + (t & 1) * STAGE2;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      half8 af[4], bf[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) af[i] = tr_frag(sb + aoff[i] + ks * 32 * ROWB2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bf[i] = tr_frag(sb + boff[i] + ks * 32 * ROWB2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- split-K reduction: D[row = co 4g+j][col = n l15]
+  const int l15 = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n_base + wn * 64 + j * 16 + l15;
+      if (n >= a.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co_base + wm * 64 + i * 16 + g * 4 + r;
+        if (co < a.Cout) atomicAdd(a.dw + (long)co * a.N + n, acc[i][j][r]);
+      }
+    }
+}
+
+}  // namespace
+
+int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
+                      int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, float* dw,
+                      const half_t* zero, hipStream_t s) {
+  if ((ksize != 1 && ksize != 3) || Cin % 8 || Cout % 8 || lddz % 8 || ldx % 8) return -1;
+  WgradArgs a{};
+  a.dz = dz; a.dz_bstride = dz_bstride; a.lddz = lddz; a.x = x; a.x_bstride = x_bstride; a.ldx = ldx;
+  a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
+  a.ksize = ksize; a.stride = stride; a.pad = ksize / 2;
+  a.M = B * Ho * Wo;
+  if ((long)B * Ho * Wo >= (1 << 24)) return -1;
+  a.N = ksize * ksize * Cin;
+  a.dw = dw; a.zero = zero;
+  const int tiles = ((Cout + 127) / 128) * ((a.N + 127) / 128);
+  const int steps_total = (a.M + KST - 1) / KST;
+  int splitk = (1024 + tiles - 1) / tiles;   // ~2 waves of blocks over 256 CUs x 2 resident blocks
+  if (splitk > steps_total) splitk = steps_total;
+  if (splitk < 1) splitk = 1;
+  a.steps_per_split = (steps_total + splitk - 1) / splitk;
+  a.splitk = (steps_total + a.steps_per_split - 1) / a.steps_per_split;
+  hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * a.N * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  const dim3 grid(tiles * a.splitk), block(256);
+  const int lds = 2 * STAGE2;
+  if (ksize == 1) {
+    hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, lds, s, a);
+  } else {
+    hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, lds, s, a);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace m355

@@ -896,6 +896,22 @@ int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const floa
   return M355_OK;
 }
 
+int m355_conv2d_wgrad(const void* d_x, const void* d_dy, int B, int H, int W, int cin, int cout, int k, int stride,
+                      float* d_dw, void* stream) {
+  if (!d_x || !d_dy || !d_dw) return set_err(M355_ERR_INVALID, "null pointer");
+  if ((k != 1 && k != 3) || (stride != 1 && stride != 2)) return set_err(M355_ERR_INVALID, "wgrad supports k in {1,3}, stride in {1,2}");
+  static half_t* zero_page = nullptr;  // 256 zero bytes, allocated once per process
+  if (!zero_page) {
+    HIP_TRYG(hipMalloc((void**)&zero_page, 256));
+    HIP_TRYG(hipMemset(zero_page, 0, 256));
+  }
+  const int pad = k / 2;
+  const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const int rc = launch_conv_wgrad((const half_t*)d_dy, (long)Ho * Wo * cout, cout, (const half_t*)d_x, (long)H * W * cin,
+                                   cin, B, H, W, cin, Ho, Wo, cout, k, stride, d_dw, zero_page, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "wgrad launch failed: " + std::to_string(rc));
+}
+
 int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const float* d_gamma, const float* d_beta,
                            float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream) {
   if (!d_z || !d_gamma || !d_beta || !d_y || !d_mean || !d_invstd || !d_ws) return set_err(M355_ERR_INVALID, "null pointer");

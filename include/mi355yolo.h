@@ -134,6 +134,11 @@ int m355_conv2d_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, cons
  * FORWARD weight fp32 (cout,cin,k,k) on the host.                                                   [sync] */
 int m355_conv2d_dgrad(const void* d_dy_f16_nhwc, int B, int H, int W, int cin, const float* h_w, int cout, int k,
                       int stride, void* d_dx_f16_nhwc, void* stream);
+/* Weight gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2) (SURVEY A13 backward): X fp16 NHWC (B,H,W,cin),
+ * dY fp16 NHWC (B,Ho,Wo,cout) -> dW fp32 DEVICE buffer in KRSC order (cout, k, k, cin) = the packed forward
+ * weight order; zeroed and accumulated (split-K float atomics) by the call.                          [async] */
+int m355_conv2d_wgrad(const void* d_x_f16_nhwc, const void* d_dy_f16_nhwc, int B, int H, int W, int cin, int cout,
+                      int k, int stride, float* d_dw_krsc, void* stream);
 /* Train-mode BatchNorm2d (batch statistics, biased variance, eps) + optional SiLU on fp16 NHWC (B,H,W,C)
  * (SURVEY A13): y = act(gamma * (z - mean) * invstd + beta).  gamma/beta/mean/invstd/ws are DEVICE fp32 arrays;
  * d_ws is a 2*C float workspace (sum, sum of squares); d_mean/d_invstd receive the saved statistics. */

@@ -85,3 +85,36 @@ def test_bn_silu_train_fwd_bwd(shape, act, cuda_device):
     assert rel_l2(d_dz.float().cpu().permute(0, 3, 1, 2), z.grad) <= 2e-3
     assert rel_l2(d_gb[:Cc].cpu(), beta.grad) <= 1e-3
     assert rel_l2(d_gb[Cc:].cpu(), gamma.grad) <= 1e-3
+
+
+WGRAD_CASES = [
+    # B, H, W, cin, cout, k, stride
+    (2, 16, 16, 64, 64, 3, 1),
+    (2, 20, 24, 32, 64, 3, 1),        # Cin = 32: an n-tile spans four taps
+    (3, 17, 13, 128, 128, 3, 1),      # ragged pixel count (M not a multiple of 64)
+    (2, 32, 32, 64, 128, 3, 2),
+    (2, 16, 16, 256, 128, 1, 1),
+    (2, 16, 16, 96, 48, 1, 1),        # ragged channel tiles on both sides
+    (8, 40, 40, 128, 224, 3, 1),      # many split-K blocks
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_CASES)
+def test_conv2d_wgrad(case, cuda_device):
+    from defectdetection_viaobjectdetection_amd import _capi
+    B, H, W, cin, cout, k, s = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(B, cin, H, W, generator=g).half().float()
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride=s, padding=k // 2)
+    dy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).contiguous()            # KRSC
+    d_x, d_dy = nhwc16(x, cuda_device), nhwc16(dy, cuda_device)
+    d_dw = torch.full((cout, k, k, cin), float("nan"), dtype=torch.float32, device=cuda_device)
+    _capi.check(_capi.lib.m355_conv2d_wgrad(_p(d_x), _p(d_dy), B, H, W, cin, cout, k, s, _p(d_dw),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    got = d_dw.cpu()
+    assert torch.isfinite(got).all()
+    assert rel_l2(got, ref) <= 1e-3
