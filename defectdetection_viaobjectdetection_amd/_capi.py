@@ -31,6 +31,25 @@ class OpInfo(C.Structure):
                 ("bytes_per_image", C.c_double), ("weight_bytes", C.c_double)]
 
 
+class ConvLaunchArgs(C.Structure):
+    """m355_conv_args (include/mi355yolo.h)."""
+    _fields_ = [("x", C.c_void_p), ("x_bstride", C.c_int64), ("ldx", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32),
+                ("cin", C.c_int32), ("w_packed", C.c_void_p), ("kpad", C.c_int32), ("bias", C.c_void_p),
+                ("y", C.c_void_p), ("y_bstride", C.c_int64), ("ldy", C.c_int32), ("ho", C.c_int32), ("wo", C.c_int32),
+                ("cout", C.c_int32), ("res", C.c_void_p), ("r_bstride", C.c_int64), ("ldr", C.c_int32),
+                ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("batch", C.c_int32),
+                ("act", C.c_int32), ("out_f32", C.c_int32), ("convt_co", C.c_int32), ("tmode", C.c_int32),
+                ("zero_page", C.c_void_p)]
+
+
+class WgradLaunchArgs(C.Structure):
+    """m355_wgrad_args (include/mi355yolo.h)."""
+    _fields_ = [("dz", C.c_void_p), ("dz_bstride", C.c_int64), ("lddz", C.c_int32), ("x", C.c_void_p),
+                ("x_bstride", C.c_int64), ("ldx", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("cin", C.c_int32),
+                ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
+                ("pad", C.c_int32), ("batch", C.c_int32), ("dw", C.c_void_p), ("zero_page", C.c_void_p)]
+
+
 # symbol -> (restype, argtypes); every entry of include/mi355yolo.h
 _P = C.c_void_p
 _F = C.POINTER(C.c_float)
@@ -67,6 +86,16 @@ SIGNATURES = {
     "m355_upsample2x": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_head_decode": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_nms": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P]),
+    "m355_conv_launch": (C.c_int, [C.POINTER(ConvLaunchArgs), _P]),
+    "m355_wgrad_launch": (C.c_int, [C.POINTER(WgradLaunchArgs), _P]),
+    "m355_bn_train_fwd_launch": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, C.c_int32,
+                                           _P, C.c_int32, _P, _P, _P, _P]),
+    "m355_bn_train_bwd_launch": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32,
+                                           _P, C.c_int32, _P, _P]),
+    "m355_sppf_pool_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_int32, _P]),
+    "m355_upsample2x_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, _P]),
     "m355_proto_masks": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
 }
 

@@ -77,13 +77,13 @@ int launch_proto_masks(const float* dets, const int* counts, const half_t* proto
 
 // weight gradient (conv_wgrad.hip): dw fp32 [Cout][k*k*Cin] (KRSC), zeroed + accumulated by the call
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
-                      int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, float* dw,
+                      int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
                       const half_t* zero, hipStream_t s);
 
 // train-mode BatchNorm + SiLU (train_kernels.hip)
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
-                             float eps, half_t* y, int ldy, float* sums, float* mean_out, float* invstd_out, int act,
-                             hipStream_t s);
+                             float eps, half_t* y, int ldy, const half_t* res, int ldr, float* sums, float* mean_out,
+                             float* invstd_out, int act, hipStream_t s);
 int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int ldz, int lddy, int C, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, float* rsum, half_t* dz,
                              int lddz, int act, hipStream_t s);

@@ -102,11 +102,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   int ld_tile = lb;         // loader cursor: tile, K step within the tile, global stage count
   int ld_t = 0, ld_g = 0;
 
-  auto loader_setup = [&](int tile) {
+  auto loader_setup = [&](int tile) __attribute__((always_inline)) {
     int tile_px, tile_ch;
     fast_divmod(tile, tiles_ch, inv_tch, tile_px, tile_ch);
     const int px_base = tile_px * BPX, ch_base = tile_ch * BCH;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int i = 0; i < A_IT; ++i) {
       const int prow = wave * (BPX / 4) + i * 8 + lrow;
       const int m = px_base + prow;
@@ -116,44 +116,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       fast_divmod(mm, HoWo, inv_howo, b, pix);
       fast_divmod(pix, a.Wo, inv_wo, ho, wo);
       unsigned mk = 0;
-      if (KS == 3 && a.tmode) {
-        // dgrad of a stride-2 conv: output pixel (ho, wo) is the forward INPUT pixel; tap (kh, kw) reads
-        // dY[(ho + 1 - kh) / 2][(wo + 1 - kw) / 2] when the parities match.  For valid taps
-        // (ho + 1 - kh) / 2 == ((ho + 1) >> 1) - (kh >> 1), so the address stays base + per-tap offset.
-        const int hb = (ho + 1) >> 1, wb = (wo + 1) >> 1;
-        rowoff[i] = (long)b * a.x_bstride + ((long)hb * a.Wi + wb) * a.ldx;
-        const unsigned ph = (unsigned)(ho + 1) & 1u, pw = (unsigned)(wo + 1) & 1u;
-        unsigned rv = 0, cv = 0;
-        if (ph) {
-          rv = ((unsigned)hb < (unsigned)a.Hi) ? 2u : 0u;                       // kh = 1
-        } else {
-          rv = (((unsigned)hb < (unsigned)a.Hi) ? 1u : 0u) | (((unsigned)(hb - 1) < (unsigned)a.Hi) ? 4u : 0u);  // kh = 0, 2
-        }
-        if (pw) {
-          cv = ((unsigned)wb < (unsigned)a.Wi) ? 2u : 0u;
-        } else {
-          cv = (((unsigned)wb < (unsigned)a.Wi) ? 1u : 0u) | (((unsigned)(wb - 1) < (unsigned)a.Wi) ? 4u : 0u);
-        }
-        mk = ((rv & 1u) ? cv : 0u) | ((rv & 2u) ? (cv << 3) : 0u) | ((rv & 4u) ? (cv << 6) : 0u);
-        if (!mv) mk = 0;
-        rowmask[i] = mk;
-        continue;
-      }
       const int hi0 = ho * a.stride - a.pad;
       const int wi0 = wo * a.stride - a.pad;
-      rowoff[i] = (long)b * a.x_bstride + ((long)hi0 * a.Wi + wi0) * a.ldx;
+      long off = (long)b * a.x_bstride + ((long)hi0 * a.Wi + wi0) * a.ldx;
+      // NOTE: keep this loop body free of inner loops / continue: hipcc then fails to unroll the row loop for
+      // A_IT = 8 and sends rowoff[] / rowmask[] to scratch (5x slower kernel).
       if (KS == 1) {
-        mk = mv ? 1u : 0u;
+        mk = 1u;
       } else {
-        // bit kh*3+kw: tap inside the image (straight-line: a nested tap loop defeats full unrolling and
-        // sends rowoff[]/rowmask[] to scratch)
-        const unsigned rv = ((unsigned)hi0 < (unsigned)a.Hi ? 1u : 0u) | ((unsigned)(hi0 + 1) < (unsigned)a.Hi ? 2u : 0u) |
-                            ((unsigned)(hi0 + 2) < (unsigned)a.Hi ? 4u : 0u);
-        const unsigned cv = ((unsigned)wi0 < (unsigned)a.Wi ? 1u : 0u) | ((unsigned)(wi0 + 1) < (unsigned)a.Wi ? 2u : 0u) |
-                            ((unsigned)(wi0 + 2) < (unsigned)a.Wi ? 4u : 0u);
-        mk = ((rv & 1u) ? cv : 0u) | ((rv & 2u) ? (cv << 3) : 0u) | ((rv & 4u) ? (cv << 6) : 0u);
-        if (!mv) mk = 0;
+        // bit kh*KS+kw: tap inside the image
+        const unsigned r0 = (unsigned)hi0 < (unsigned)a.Hi ? 1u : 0u, r1 = (unsigned)(hi0 + 1) < (unsigned)a.Hi ? 2u : 0u;
+        const unsigned c0 = (unsigned)wi0 < (unsigned)a.Wi ? 1u : 0u, c1 = (unsigned)(wi0 + 1) < (unsigned)a.Wi ? 2u : 0u;
+        if (KS == 3) {
+          unsigned rv = r0 | r1 | ((unsigned)(hi0 + 2) < (unsigned)a.Hi ? 4u : 0u);
+          unsigned cv = c0 | c1 | ((unsigned)(wi0 + 2) < (unsigned)a.Wi ? 4u : 0u);
+          // tmode = dgrad of a stride-2 conv: output pixel (ho, wo) is the forward INPUT pixel; tap (kh, kw)
+          // reads dY[(ho + 1 - kh) / 2][(wo + 1 - kw) / 2] when the parities match.  For valid taps
+          // (ho + 1 - kh) / 2 == ((ho + 1) >> 1) - (kh >> 1), so the address stays base + per-tap offset.
+          const int hb = (ho + 1) >> 1, wb = (wo + 1) >> 1;
+          const unsigned h_in = (unsigned)hb < (unsigned)a.Hi ? 1u : 0u, h_in1 = (unsigned)(hb - 1) < (unsigned)a.Hi ? 1u : 0u;
+          const unsigned w_in = (unsigned)wb < (unsigned)a.Wi ? 1u : 0u, w_in1 = (unsigned)(wb - 1) < (unsigned)a.Wi ? 1u : 0u;
+          const unsigned rvt = ((ho + 1) & 1) ? (h_in << 1) : (h_in | (h_in1 << 2));
+          const unsigned cvt = ((wo + 1) & 1) ? (w_in << 1) : (w_in | (w_in1 << 2));
+          const bool tm = a.tmode != 0;
+          rv = tm ? rvt : rv;
+          cv = tm ? cvt : cv;
+          off = tm ? ((long)b * a.x_bstride + ((long)hb * a.Wi + wb) * a.ldx) : off;
+          mk = ((rv & 1u) ? cv : 0u) | ((rv & 2u) ? (cv << 3) : 0u) | ((rv & 4u) ? (cv << 6) : 0u);
+        } else {
+          const unsigned cv = c0 | c1;
+          mk = (r0 ? cv : 0u) | (r1 ? (cv << 2) : 0u);
+        }
       }
+      if (!mv) mk = 0;
+      rowoff[i] = off;
       rowmask[i] = mk;
     }
     // weights: LDS row R (tile-local) holds the weight row of the channel the MFMA row maps to, so that
@@ -174,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   };
 
   // issue the LDS-DMA of the stage under the loader cursor into buffer (ld_g & 1), advance the cursor
-  auto stage_next = [&]() {
+  auto stage_next = [&]() __attribute__((always_inline)) {
     const int t = ld_t;
     char* sb = smem + (ld_g & 1) * STAGE;
     const bool skip_w = (a.dbg & 2) && ld_g > 1, skip_a = (a.dbg & 1) && ld_g > 1;
@@ -191,12 +187,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     } else {
       tap = (int)(((float)kq + 0.5f) * inv_cin);
       cin = kq - tap * a.Cin;
-      const int kh = (tap * 11) >> 5;  // tap/3 for tap < 12
-      const int kw = tap - kh * 3;
+      const int kh = (KS == 3) ? ((tap * 11) >> 5) : (tap >> 1);  // tap / KS for the few taps that exist
+      const int kw = tap - kh * KS;
       tapoff = a.tmode ? (cin - ((kh >> 1) * a.Wi + (kw >> 1)) * a.ldx) : ((kh * a.Wi + kw) * a.ldx + cin);
     }
     char* ab = sb + BCH * ROWB;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int i = 0; i < A_IT; ++i) {
       const bool ok = (rowmask[i] >> tap) & 1u;
       const half_t* src = ok ? (a.x + rowoff[i] + tapoff) : a.zero;
@@ -250,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   //         done reading stage gs -> issue ds_reads ks=0(gs+1), LDS-DMA for stage gs+2 into buffer
   //         gs&1 -> 16 MFMA ks=1(gs)
   int gs = 0;
-  auto kstep = [&]() {
+  auto kstep = [&]() __attribute__((always_inline)) {
     const char* sb = smem + (gs & 1) * STAGE;
     const char* sn = smem + ((gs + 1) & 1) * STAGE;
 #pragma unroll
@@ -391,21 +387,15 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   }
   const dim3 grid(grid_x), block(256);
   hipError_t e;
-  if (a.ksize == 1) {
-    auto k = conv_igemm_kernel<MT, NT, WCH, WPX, 1>;
-    if (LDS > 65536) {
-      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, grid, block, LDS, s, a);
-  } else {
-    auto k = conv_igemm_kernel<MT, NT, WCH, WPX, 3>;
-    if (LDS > 65536) {
-      e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      if (e != hipSuccess) return (int)e;
-    }
-    hipLaunchKernelGGL(k, grid, block, LDS, s, a);
+  auto k1 = conv_igemm_kernel<MT, NT, WCH, WPX, 1>;
+  auto k2 = conv_igemm_kernel<MT, NT, WCH, WPX, 2>;
+  auto k3 = conv_igemm_kernel<MT, NT, WCH, WPX, 3>;
+  auto k = a.ksize == 1 ? k1 : (a.ksize == 2 ? k2 : k3);
+  if (LDS > 65536) {
+    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) return (int)e;
   }
+  hipLaunchKernelGGL(k, grid, block, LDS, s, a);
   return (int)hipGetLastError();
 }
 
@@ -426,7 +416,8 @@ int conv_pick_tile(int cout, long M) {
 }
 
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s) {
-  if (a.ksize != 1 && a.ksize != 3) return -1;
+  if (a.ksize < 1 || a.ksize > 3) return -1;
+  if (a.ksize == 2 && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // only the ConvT-dgrad form
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
   if (a.M >= (1 << 24)) return -1;  // fast_divmod range
   int tile = force_tile & 0xff;

@@ -181,13 +181,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 }  // namespace
 
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
-                      int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, float* dw,
+                      int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
                       const half_t* zero, hipStream_t s) {
-  if ((ksize != 1 && ksize != 3) || Cin % 8 || Cout % 8 || lddz % 8 || ldx % 8) return -1;
+  if (ksize < 1 || ksize > 3 || Cin % 8 || Cout % 8 || lddz % 8 || ldx % 8) return -1;
   WgradArgs a{};
   a.dz = dz; a.dz_bstride = dz_bstride; a.lddz = lddz; a.x = x; a.x_bstride = x_bstride; a.ldx = ldx;
   a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
-  a.ksize = ksize; a.stride = stride; a.pad = ksize / 2;
+  a.ksize = ksize; a.stride = stride; a.pad = pad;
   a.M = B * Ho * Wo;
   if ((long)B * Ho * Wo >= (1 << 24)) return -1;
   a.N = ksize * ksize * Cin;
@@ -205,6 +205,8 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
   const int lds = 2 * STAGE2;
   if (ksize == 1) {
     hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, block, lds, s, a);
+  } else if (ksize == 2) {
+    hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, block, lds, s, a);
   } else {
     hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, lds, s, a);
   }

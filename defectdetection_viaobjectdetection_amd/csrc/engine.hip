@@ -908,7 +908,7 @@ int m355_conv2d_wgrad(const void* d_x, const void* d_dy, int B, int H, int W, in
   const int pad = k / 2;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   const int rc = launch_conv_wgrad((const half_t*)d_dy, (long)Ho * Wo * cout, cout, (const half_t*)d_x, (long)H * W * cin,
-                                   cin, B, H, W, cin, Ho, Wo, cout, k, stride, d_dw, zero_page, (hipStream_t)stream);
+                                   cin, B, H, W, cin, Ho, Wo, cout, k, stride, pad, d_dw, zero_page, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "wgrad launch failed: " + std::to_string(rc));
 }
 
@@ -916,7 +916,7 @@ int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const fl
                            float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream) {
   if (!d_z || !d_gamma || !d_beta || !d_y || !d_mean || !d_invstd || !d_ws) return set_err(M355_ERR_INVALID, "null pointer");
   const int rc = launch_bn_silu_train_fwd((const half_t*)d_z, (long)B * H * W, C, C, d_gamma, d_beta, eps, (half_t*)d_y, C,
-                                          d_ws, d_mean, d_invstd, act, (hipStream_t)stream);
+                                          nullptr, 0, d_ws, d_mean, d_invstd, act, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn fwd launch failed: " + std::to_string(rc));
 }
 
@@ -1003,6 +1003,64 @@ int m355_proto_masks(const float* d_dets, const int* d_counts, const void* d_pro
   const int rc = launch_proto_masks(d_dets, d_counts, (const half_t*)d_protos, B, max_det, 32, mh, mw, in_h, in_w,
                                     d_masks, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "mask launch failed: " + std::to_string(rc));
+}
+
+int m355_conv_launch(const m355_conv_args* c, void* stream) {
+  if (!c || !c->x || !c->w_packed || !c->bias || !c->y || !c->zero_page) return set_err(M355_ERR_INVALID, "null pointer");
+  ConvArgs a{};
+  a.x = (const half_t*)c->x; a.x_bstride = c->x_bstride; a.ldx = c->ldx; a.Hi = c->hi; a.Wi = c->wi; a.Cin = c->cin;
+  a.w = (const half_t*)c->w_packed; a.Kpad = c->kpad; a.bias = c->bias;
+  a.y = c->y; a.y_bstride = c->y_bstride; a.ldy = c->ldy; a.Ho = c->ho; a.Wo = c->wo; a.Cout = c->cout;
+  a.res = (const half_t*)c->res; a.r_bstride = c->r_bstride; a.ldr = c->ldr;
+  a.ksize = c->ksize; a.stride = c->stride; a.pad = c->pad; a.M = c->batch * c->ho * c->wo;
+  a.act = c->act; a.out_f32 = c->out_f32; a.convt_co = c->convt_co; a.tmode = c->tmode;
+  a.zero = (const half_t*)c->zero_page;
+  int rc;
+  if (!a.tmode && conv3x3_halo_ok(a))
+    rc = launch_conv3x3_halo(a, 0, (hipStream_t)stream);
+  else
+    rc = launch_conv_igemm(a, TILE_AUTO, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "conv launch failed: " + std::to_string(rc));
+}
+
+int m355_wgrad_launch(const m355_wgrad_args* w, void* stream) {
+  if (!w || !w->dz || !w->x || !w->dw || !w->zero_page) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_conv_wgrad((const half_t*)w->dz, w->dz_bstride, w->lddz, (const half_t*)w->x, w->x_bstride, w->ldx,
+                                   w->batch, w->hi, w->wi, w->cin, w->ho, w->wo, w->cout, w->ksize, w->stride, w->pad,
+                                   w->dw, (const half_t*)w->zero_page, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "wgrad launch failed: " + std::to_string(rc));
+}
+
+int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C, const float* gamma, const float* beta,
+                             float eps, int32_t act, void* y, int32_t ldy, const void* res, int32_t ldr, float* mean,
+                             float* invstd, float* ws, void* stream) {
+  if (!z || !gamma || !beta || !y || !mean || !invstd || !ws) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_bn_silu_train_fwd((const half_t*)z, npix, ldz, C, gamma, beta, eps, (half_t*)y, ldy,
+                                          (const half_t*)res, ldr, ws, mean, invstd, act, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn fwd launch failed: " + std::to_string(rc));
+}
+
+int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_t ldz, int32_t lddy, int32_t C,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t act,
+                             void* dz, int32_t lddz, float* dbeta_dgamma, void* stream) {
+  if (!z || !dy || !mean || !invstd || !gamma || !beta || !dz || !dbeta_dgamma) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_bn_silu_train_bwd((const half_t*)z, (const half_t*)dy, npix, ldz, lddy, C, mean, invstd, gamma, beta,
+                                          dbeta_dgamma, (half_t*)dz, lddz, act, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn bwd launch failed: " + std::to_string(rc));
+}
+
+int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
+                          int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_sppf_pool((const half_t*)x, x_bstride, ldx, (half_t*)y, y_bstride, ldy, B, H, W, C, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "sppf launch failed: " + std::to_string(rc));
+}
+
+int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
+                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
+  if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_upsample2x((const half_t*)x, x_bstride, ldx, (half_t*)y, y_bstride, ldy, B, H, W, C, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "upsample launch failed: " + std::to_string(rc));
 }
 
 }  // extern "C"

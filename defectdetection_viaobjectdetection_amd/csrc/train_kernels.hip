@@ -53,7 +53,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const half_t* z, l
 __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t* z, long npix, int ldz, int C,
                                                                    const float* sums, const float* gamma,
                                                                    const float* beta, float eps, half_t* y, int ldy,
-                                                                   float* mean_out, float* invstd_out, int act) {
+                                                                   const half_t* res, int ldr, float* mean_out,
+                                                                   float* invstd_out, int act) {
   const int cg = C / 8;
   const long total = npix * cg;
   const float inv_n = 1.0f / (float)npix;
@@ -61,6 +62,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t*
     const long p = i / cg;
     const int g = (int)(i - p * cg);
     const half8 v = *(const half8*)(z + p * ldz + g * 8);
+    half8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (res) rv = *(const half8*)(res + p * ldr + g * 8);
     half8 o;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -69,7 +72,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t*
       const float var = fmaxf(sums[C + c] * inv_n - m * m, 0.f);
       const float is = rsqrtf(var + eps);
       const float u = gamma[c] * ((float)v[j] - m) * is + beta[c];
-      o[j] = (half_t)(act ? u * sigmoid_f(u) : u);
+      o[j] = (half_t)((act ? u * sigmoid_f(u) : u) + (float)rv[j]);
       if (p == 0 && mean_out) {
         mean_out[c] = m;
         invstd_out[c] = is;
@@ -170,8 +173,8 @@ int grid_for(long work_items) {
 
 // sums: device float[2C] zeroed by this call (hipMemsetAsync on the same stream)
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
-                             float eps, half_t* y, int ldy, float* sums, float* mean_out, float* invstd_out, int act,
-                             hipStream_t s) {
+                             float eps, half_t* y, int ldy, const half_t* res, int ldr, float* sums, float* mean_out,
+                             float* invstd_out, int act, hipStream_t s) {
   if (C % 8 || ldz % 8 || ldy % 8 || C / 8 > BN_THREADS) return -1;
   hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
@@ -179,7 +182,7 @@ int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const f
   hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
                      BN_THREADS * 16 * sizeof(float), s, z, npix, ldz, C, sums);
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(BN_THREADS), 0, s, z, npix, ldz, C, sums,
-                     gamma, beta, eps, y, ldy, mean_out, invstd_out, act);
+                     gamma, beta, eps, y, ldy, res, ldr, mean_out, invstd_out, act);
   return (int)hipGetLastError();
 }
 

@@ -169,6 +169,44 @@ int m355_nms(const float* d_preds, int B, int A, int nc, int nm, float conf, flo
 int m355_proto_masks(const float* d_dets, const int* d_counts, const void* d_protos, int B, int max_det,
                      int mh, int mw, int in_h, int in_w, uint8_t* d_masks, void* stream);
 
+/* ---- raw strided launches (asynchronous; every pointer is a DEVICE pointer) --------------------------------
+ * Used by the training orchestrator (defectdetection_viaobjectdetection_amd/train_engine.py) to run the kernels
+ * on channel slices of shared NHWC buffers.  Strides are in ELEMENTS of the tensor's dtype. */
+typedef struct {
+  const void* x; int64_t x_bstride; int32_t ldx; int32_t hi, wi, cin;   /* input slice (fp16 NHWC) */
+  const void* w_packed; int32_t kpad;   /* fp16 [ceil128(cout)][kpad], K = (kh*k+kw)*cin + ci, kpad % 64 == 0 */
+  const float* bias;                    /* fp32 [ceil128(cout)] */
+  void* y; int64_t y_bstride; int32_t ldy; int32_t ho, wo, cout;          /* output slice (fp16, or fp32 if out_f32) */
+  const void* res; int64_t r_bstride; int32_t ldr;                        /* optional residual added after act */
+  int32_t ksize, stride, pad, batch;
+  int32_t act, out_f32, convt_co, tmode;
+  const void* zero_page;                /* >= 16 zero bytes */
+} m355_conv_args;
+/* Convolution / dgrad / ConvTranspose forward on the implicit-GEMM or halo kernel (chosen by shape). */
+int m355_conv_launch(const m355_conv_args* a, void* stream);
+
+typedef struct {
+  const void* dz; int64_t dz_bstride; int32_t lddz;   /* dY slice (fp16 NHWC), spatial ho x wo, cout channels */
+  const void* x; int64_t x_bstride; int32_t ldx;      /* forward input slice, spatial hi x wi, cin channels */
+  int32_t hi, wi, cin, ho, wo, cout;
+  int32_t ksize, stride, pad, batch;
+  float* dw;                                          /* fp32 [cout][ksize*ksize*cin] (KRSC), zeroed by the call */
+  const void* zero_page;
+} m355_wgrad_args;
+int m355_wgrad_launch(const m355_wgrad_args* a, void* stream);
+
+/* Train-mode BN(+SiLU)(+residual) on slices: y = act(bn(z)) + res. */
+int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C, const float* gamma, const float* beta,
+                             float eps, int32_t act, void* y, int32_t ldy, const void* res, int32_t ldr, float* mean,
+                             float* invstd, float* ws, void* stream);
+int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_t ldz, int32_t lddy, int32_t C,
+                             const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t act,
+                             void* dz, int32_t lddz, float* dbeta_dgamma, void* stream);
+int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
+                          int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
+                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
