@@ -1,0 +1,429 @@
+"""Train-mode forward / backward of YOLOv8-seg on the HIP kernels (SURVEY.md A13, A16 building blocks).
+
+Stands where ``SegmentationModel.forward`` in training mode + PyTorch autograd stand upstream (call site
+/root/reference/BscanBased/yolo_seg_train.py:12-19).  The graph, buffers and the order of kernel launches are
+orchestrated here in Python over the raw C-ABI launches of ``libmi355yolo.so``:
+
+  forward  per Conv block : implicit-GEMM / halo conv (no bias, no act) -> z ; train-mode BatchNorm (batch
+                            statistics) + SiLU (+ residual) -> activation slice      [conv_launch, bn_train_fwd]
+  backward per Conv block : BN+SiLU backward -> dz, dgamma, dbeta ; wgrad (pixel-axis GEMM) -> dW ; dgrad
+                            (same conv kernels, flipped / transposed-stride weights) accumulated into the
+                            producer's gradient slice                                [bn_train_bwd, wgrad, conv]
+
+Every FLOP-carrying op runs in the hand-written kernels.  PyTorch is used for buffers, for re-packing the fp32
+master weights to fp16 GEMM layouts after an optimizer step, and for the byte-moving leftovers of the backward
+pass that are <1 % of the traffic (residual / concat gradient adds, 2x2 upsample-sum, SPPF max-pool routing,
+bias-gradient sums).  Master parameters are fp32 in KRSC layout = the layout wgrad produces.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from ._capi import ConvLaunchArgs, WgradLaunchArgs, check, lib
+from .spec import BN_EPS, NM, REG_MAX, SCALES, ConvSpec, _make_divisible, conv_specs
+
+BN_MOMENTUM = 0.03
+
+
+def _ceil(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class Slice:
+    t: int
+    off: int
+    c: int
+
+
+class TrainEngine:
+    def __init__(self, scale: str = "n", nc: int = 1, imgsz: Tuple[int, int] = (640, 640), batch: int = 2,
+                 device: int = 0):
+        if not torch.cuda.is_available():
+            raise RuntimeError("TrainEngine needs a gfx950 GPU; there is no CPU fallback")
+        self.dev = torch.device("cuda", device)
+        self.scale, self.nc, self.imgsz, self.B = scale, nc, tuple(imgsz), batch
+        self.specs: Dict[str, ConvSpec] = {s.name: s for s in conv_specs(scale, nc)}
+        self.tensors: List[torch.Tensor] = []
+        self.gtensors: List[Optional[torch.Tensor]] = []
+        self.ops: List[dict] = []
+        self.params: Dict[str, torch.Tensor] = {}
+        self.grads: Dict[str, torch.Tensor] = {}
+        self.packed: Dict[str, torch.Tensor] = {}
+        self.saved: Dict[str, dict] = {}
+        self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.dev)
+        self.zero_bias = torch.zeros(4096, dtype=torch.float32, device=self.dev)
+        self._build()
+
+    # ------------------------------------------------------------------ graph
+    def _tensor(self, H, W, Cc) -> int:
+        self.tensors.append(torch.zeros((self.B, H, W, Cc), dtype=torch.float16, device=self.dev))
+        self.gtensors.append(None)
+        return len(self.tensors) - 1
+
+    def _conv(self, name, src: Slice, dst: Slice, res: Optional[Slice] = None):
+        s = self.specs[name]
+        assert s.cin == src.c or (s.cin == 3 and src.c == 8), (name, s.cin, src.c)
+        self.ops.append(dict(kind="conv", name=name, src=src, dst=dst, res=res, k=s.k, s=s.stride))
+
+    def _c2f(self, name, src: Slice, dst: Slice, n: int, shortcut: bool):
+        H, W = self.tensors[src.t].shape[1:3]
+        c = dst.c // 2
+        cat = self._tensor(H, W, (2 + n) * c)
+        self._conv(f"{name}.cv1", src, Slice(cat, 0, 2 * c))
+        for j in range(n):
+            tmp = self._tensor(H, W, c)
+            s_in = Slice(cat, (1 + j) * c, c)
+            self._conv(f"{name}.m.{j}.cv1", s_in, Slice(tmp, 0, c))
+            self._conv(f"{name}.m.{j}.cv2", Slice(tmp, 0, c), Slice(cat, (2 + j) * c, c), s_in if shortcut else None)
+        self._conv(f"{name}.cv2", Slice(cat, 0, (2 + n) * c), dst)
+
+    def _build(self):
+        depth, width, maxc = SCALES[self.scale]
+        ch = lambda c: _make_divisible(min(c, maxc) * width, 8)  # noqa: E731
+        rep = lambda n: max(round(n * depth), 1) if n > 1 else n  # noqa: E731
+        c64, c128, c256, c512, c1024 = ch(64), ch(128), ch(256), ch(512), ch(1024)
+        H, W = self.imgsz
+        T = self._tensor
+        self.x8 = T(H, W, 8)  # input: 3 channels / 255 in fp16, zero-padded to 8 channels
+        cat11 = T(H // 16, W // 16, c1024 + c512)
+        cat14 = T(H // 8, W // 8, c512 + c256)
+        cat17 = T(H // 16, W // 16, c256 + c512)
+        cat20 = T(H // 32, W // 32, c512 + c1024)
+        x4, x6 = Slice(cat14, c512, c256), Slice(cat11, c1024, c512)
+        x9, x12 = Slice(cat20, c512, c1024), Slice(cat17, c256, c512)
+        t0 = T(H // 2, W // 2, c64)
+        self._conv("model.0", Slice(self.x8, 0, 8), Slice(t0, 0, c64))
+        t1 = T(H // 4, W // 4, c128)
+        self._conv("model.1", Slice(t0, 0, c64), Slice(t1, 0, c128))
+        t2 = T(H // 4, W // 4, c128)
+        self._c2f("model.2", Slice(t1, 0, c128), Slice(t2, 0, c128), rep(3), True)
+        t3 = T(H // 8, W // 8, c256)
+        self._conv("model.3", Slice(t2, 0, c128), Slice(t3, 0, c256))
+        self._c2f("model.4", Slice(t3, 0, c256), x4, rep(6), True)
+        t5 = T(H // 16, W // 16, c512)
+        self._conv("model.5", x4, Slice(t5, 0, c512))
+        self._c2f("model.6", Slice(t5, 0, c512), x6, rep(6), True)
+        t7 = T(H // 32, W // 32, c1024)
+        self._conv("model.7", x6, Slice(t7, 0, c1024))
+        t8 = T(H // 32, W // 32, c1024)
+        self._c2f("model.8", Slice(t7, 0, c1024), Slice(t8, 0, c1024), rep(3), True)
+        c_ = c1024 // 2
+        sp = T(H // 32, W // 32, 4 * c_)
+        self._conv("model.9.cv1", Slice(t8, 0, c1024), Slice(sp, 0, c_))
+        self.ops.append(dict(kind="pool", src=Slice(sp, 0, c_), dst=Slice(sp, c_, 3 * c_)))
+        self._conv("model.9.cv2", Slice(sp, 0, 4 * c_), x9)
+        self.ops.append(dict(kind="up", src=x9, dst=Slice(cat11, 0, c1024)))
+        self._c2f("model.12", Slice(cat11, 0, c1024 + c512), x12, rep(3), False)
+        self.ops.append(dict(kind="up", src=x12, dst=Slice(cat14, 0, c512)))
+        t15 = T(H // 8, W // 8, c256)
+        self._c2f("model.15", Slice(cat14, 0, c512 + c256), Slice(t15, 0, c256), rep(3), False)
+        self._conv("model.16", Slice(t15, 0, c256), Slice(cat17, 0, c256))
+        t18 = T(H // 16, W // 16, c512)
+        self._c2f("model.18", Slice(cat17, 0, c256 + c512), Slice(t18, 0, c512), rep(3), False)
+        self._conv("model.19", Slice(t18, 0, c512), Slice(cat20, 0, c512))
+        t21 = T(H // 32, W // 32, c1024)
+        self._c2f("model.21", Slice(cat20, 0, c512 + c1024), Slice(t21, 0, c1024), rep(3), False)
+        # head
+        feats, fch = (t15, t18, t21), (c256, c512, c1024)
+        hc2, hc3, hc4 = max(16, fch[0] // 4, REG_MAX * 4), max(fch[0], min(self.nc, 100)), max(fch[0] // 4, NM)
+        npr = ch(256)
+        hw = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+        self.level_n = [h * w for h, w in hw]
+        self.A = sum(self.level_n)
+        self.rw = 64 + self.nc + NM
+        self.raw = torch.zeros((self.B, self.A, self.rw), dtype=torch.float32, device=self.dev)
+        off = 0
+        for l in range(3):
+            f = Slice(feats[l], 0, fch[l])
+            for br, hc, cout, choff in (("cv2", hc2, 64, 0), ("cv3", hc3, self.nc, 64), ("cv4", hc4, NM, 64 + self.nc)):
+                u1, u2 = T(*hw[l], hc), T(*hw[l], hc)
+                self._conv(f"model.22.{br}.{l}.0", f, Slice(u1, 0, hc))
+                self._conv(f"model.22.{br}.{l}.1", Slice(u1, 0, hc), Slice(u2, 0, hc))
+                self.ops.append(dict(kind="plain", name=f"model.22.{br}.{l}.2", src=Slice(u2, 0, hc), cout=cout,
+                                     level_off=off, ch_off=choff, hw=hw[l]))
+            off += self.level_n[l]
+        pr1, pr2, pr3 = T(H // 8, W // 8, npr), T(H // 4, W // 4, npr), T(H // 4, W // 4, npr)
+        self.protos_t = T(H // 4, W // 4, NM)
+        self._conv("model.22.proto.cv1", Slice(t15, 0, c256), Slice(pr1, 0, npr))
+        self.ops.append(dict(kind="convt", name="model.22.proto.upsample", src=Slice(pr1, 0, npr), dst=Slice(pr2, 0, npr)))
+        self._conv("model.22.proto.cv2", Slice(pr2, 0, npr), Slice(pr3, 0, npr))
+        self._conv("model.22.proto.cv3", Slice(pr3, 0, npr), Slice(self.protos_t, 0, NM))
+
+    # ------------------------------------------------------------------ parameters
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        """Upstream-named state dict (OIHW conv weights) -> fp32 master parameters (KRSC) on the device."""
+        for s in self.specs.values():
+            if s.has_bn:
+                w = sd[f"{s.name}.conv.weight"].float().permute(0, 2, 3, 1).contiguous()
+                self.params[f"{s.name}.conv.weight"] = w.to(self.dev)
+                for p in ("weight", "bias", "running_mean", "running_var"):
+                    self.params[f"{s.name}.bn.{p}"] = sd[f"{s.name}.bn.{p}"].float().clone().to(self.dev)
+            elif s.transposed:
+                self.params[f"{s.name}.weight"] = sd[f"{s.name}.weight"].float().clone().to(self.dev)  # (cin,cout,2,2)
+                self.params[f"{s.name}.bias"] = sd[f"{s.name}.bias"].float().clone().to(self.dev)
+            else:
+                self.params[f"{s.name}.weight"] = sd[f"{s.name}.weight"].float().permute(0, 2, 3, 1).contiguous().to(self.dev)
+                self.params[f"{s.name}.bias"] = sd[f"{s.name}.bias"].float().clone().to(self.dev)
+        for k, v in self.params.items():
+            if "running_" not in k:
+                self.grads[k] = torch.zeros_like(v)
+        self.repack()
+
+    def state_dict(self) -> Dict[str, torch.Tensor]:
+        out = {}
+        for k, v in self.params.items():
+            name = k.rsplit(".", 1)[0].replace(".conv", "")
+            s = self.specs.get(name) or self.specs.get(k.rsplit(".", 2)[0])
+            if k.endswith("weight") and v.dim() == 4 and not (s and s.transposed):
+                out[k] = v.permute(0, 3, 1, 2).contiguous().cpu()
+            else:
+                out[k] = v.clone().cpu()
+        for s in self.specs.values():
+            if s.has_bn:
+                out[f"{s.name}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+        out["model.22.dfl.conv.weight"] = torch.arange(REG_MAX, dtype=torch.float32).view(1, REG_MAX, 1, 1)
+        return out
+
+    def trainable(self) -> List[Tuple[str, torch.Tensor, torch.Tensor]]:
+        return [(k, self.params[k], self.grads[k]) for k in self.grads]
+
+    @staticmethod
+    def _pad_pack(m: torch.Tensor) -> torch.Tensor:
+        rows, K = m.shape
+        out = torch.zeros((_ceil(rows, 128), _ceil(K, 64)), dtype=torch.float16, device=m.device)
+        out[:rows, :K] = m.half()
+        return out
+
+    def repack(self) -> None:
+        """fp32 master weights -> fp16 GEMM layouts: forward [Cout][(kh,kw,ci)] and dgrad [Cin][(kh',kw',co)]."""
+        for s in self.specs.values():
+            if s.transposed:
+                w = self.params[f"{s.name}.weight"]                       # (cin, cout, 2, 2)
+                self.packed[s.name + ":fwd"] = self._pad_pack(w.permute(2, 3, 1, 0).reshape(4 * s.cout, s.cin))
+                self.packed[s.name + ":dgrad"] = self._pad_pack(w.permute(0, 2, 3, 1).reshape(s.cin, 4 * s.cout))
+                continue
+            w = self.params[f"{s.name}.conv.weight" if s.has_bn else f"{s.name}.weight"]  # (cout, k, k, cin)
+            cout, cin = s.cout, s.cin
+            if cin == 3:                                                    # stem: input padded to 8 channels
+                w = F.pad(w, (0, 5))
+                cin = 8
+            if cout % 8:                                                    # class branch (nc) -> pad rows to 8
+                w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, _ceil(cout, 8) - cout))
+                cout = _ceil(cout, 8)
+            self.packed[s.name + ":fwd"] = self._pad_pack(w.reshape(cout, -1))
+            if s.cin != 3:
+                wd = w if s.stride == 2 else w.flip(1, 2)                   # stride 2 = transposed-stride gather, no flip
+                self.packed[s.name + ":dgrad"] = self._pad_pack(wd.permute(3, 1, 2, 0).reshape(cin, -1))
+
+    # ------------------------------------------------------------------ kernel plumbing
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def _slice_ptr(self, tensors, sl: Slice):
+        t = tensors[sl.t]
+        return t.data_ptr() + sl.off * t.element_size(), t.shape[1] * t.shape[2] * t.shape[3], t.shape[3]
+
+    def _conv_launch(self, x_ptr, x_bs, ldx, hi, wi, cin, w, y_ptr, y_bs, ldy, ho, wo, cout, k, stride, pad, bias=None,
+                     res_ptr=0, r_bs=0, ldr=0, act=0, out_f32=0, convt_co=0, tmode=0):
+        a = ConvLaunchArgs()
+        a.x, a.x_bstride, a.ldx, a.hi, a.wi, a.cin = x_ptr, x_bs, ldx, hi, wi, cin
+        a.w_packed, a.kpad = w.data_ptr(), w.shape[1]
+        a.bias = (bias if bias is not None else self.zero_bias).data_ptr()
+        a.y, a.y_bstride, a.ldy, a.ho, a.wo, a.cout = y_ptr, y_bs, ldy, ho, wo, cout
+        a.res, a.r_bstride, a.ldr = res_ptr, r_bs, ldr
+        a.ksize, a.stride, a.pad, a.batch = k, stride, pad, self.B
+        a.act, a.out_f32, a.convt_co, a.tmode = act, out_f32, convt_co, tmode
+        a.zero_page = self.zero_page.data_ptr()
+        check(lib.m355_conv_launch(C.byref(a), self._stream()))
+
+    def _wgrad_launch(self, dz, lddz, dz_bs, x_ptr, x_bs, ldx, hi, wi, cin, ho, wo, cout, k, stride, pad, dw):
+        a = WgradLaunchArgs()
+        a.dz, a.dz_bstride, a.lddz = dz, dz_bs, lddz
+        a.x, a.x_bstride, a.ldx = x_ptr, x_bs, ldx
+        a.hi, a.wi, a.cin, a.ho, a.wo, a.cout = hi, wi, cin, ho, wo, cout
+        a.ksize, a.stride, a.pad, a.batch = k, stride, pad, self.B
+        a.dw, a.zero_page = dw.data_ptr(), self.zero_page.data_ptr()
+        check(lib.m355_wgrad_launch(C.byref(a), self._stream()))
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, images_u8_nhwc: torch.Tensor, update_running_stats: bool = True):
+        """images uint8 (B,H,W,3) on the device.  Returns raw (B,A,64+nc+32) fp32 and protos (B,H/4,W/4,32) fp16
+        (views of engine buffers, valid until the next forward)."""
+        B = self.B
+        assert tuple(images_u8_nhwc.shape) == (B, *self.imgsz, 3) and images_u8_nhwc.dtype == torch.uint8
+        x8 = self.tensors[self.x8]
+        x8[..., :3] = (images_u8_nhwc.float() / 255.0).half()
+        st = self._stream()
+        for op in self.ops:
+            kind = op["kind"]
+            if kind == "conv":
+                name, src, dst = op["name"], op["src"], op["dst"]
+                tin, tout = self.tensors[src.t], self.tensors[dst.t]
+                hi, wi = tin.shape[1:3]
+                ho, wo = tout.shape[1:3]
+                cout = dst.c
+                sv = self.saved.setdefault(name, {})
+                if "z" not in sv:
+                    sv["z"] = torch.empty((B, ho, wo, cout), dtype=torch.float16, device=self.dev)
+                    sv["mean"] = torch.empty(cout, device=self.dev)
+                    sv["invstd"] = torch.empty(cout, device=self.dev)
+                    sv["ws"] = torch.empty(2 * cout, device=self.dev)
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                self._conv_launch(xp, xbs, ldx, hi, wi, src.c, self.packed[name + ":fwd"], sv["z"].data_ptr(), ho * wo * cout,
+                                  cout, ho, wo, cout, op["k"], op["s"], op["k"] // 2)
+                yp, _, ldy = self._slice_ptr(self.tensors, dst)
+                rp, ldr = (0, 0)
+                if op["res"] is not None:
+                    rp, _, ldr = self._slice_ptr(self.tensors, op["res"])
+                check(lib.m355_bn_train_fwd_launch(sv["z"].data_ptr(), B * ho * wo, cout, cout,
+                                                   self.params[f"{name}.bn.weight"].data_ptr(),
+                                                   self.params[f"{name}.bn.bias"].data_ptr(), BN_EPS, 1, yp, ldy, rp, ldr,
+                                                   sv["mean"].data_ptr(), sv["invstd"].data_ptr(), sv["ws"].data_ptr(), st))
+                if update_running_stats:
+                    n = B * ho * wo
+                    var = (1.0 / sv["invstd"] ** 2 - BN_EPS).clamp_(min=0) * (n / max(n - 1, 1))
+                    self.params[f"{name}.bn.running_mean"].mul_(1 - BN_MOMENTUM).add_(sv["mean"], alpha=BN_MOMENTUM)
+                    self.params[f"{name}.bn.running_var"].mul_(1 - BN_MOMENTUM).add_(var, alpha=BN_MOMENTUM)
+            elif kind == "plain":
+                name, src = op["name"], op["src"]
+                tin = self.tensors[src.t]
+                h, w = op["hw"]
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                yp = self.raw.data_ptr() + (op["level_off"] * self.rw + op["ch_off"]) * 4
+                bias = F.pad(self.params[f"{name}.bias"], (0, 128))
+                self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, self.A * self.rw, self.rw, h, w,
+                                  op["cout"], 1, 1, 0, bias=bias, out_f32=1)
+                op["_bias_keepalive"] = bias
+            elif kind == "convt":
+                name, src, dst = op["name"], op["src"], op["dst"]
+                tin, tout = self.tensors[src.t], self.tensors[dst.t]
+                h, w = tin.shape[1:3]
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
+                bias = F.pad(self.params[f"{name}.bias"], (0, 128))
+                self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, ybs, ldy, h, w, 4 * dst.c, 1, 1, 0,
+                                  bias=bias, convt_co=dst.c)
+                op["_bias_keepalive"] = bias
+            elif kind == "pool":
+                src, dst = op["src"], op["dst"]
+                t = self.tensors[src.t]
+                _, H, W, Ct = t.shape
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
+                check(lib.m355_sppf_pool_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
+            elif kind == "up":
+                src, dst = op["src"], op["dst"]
+                t = self.tensors[src.t]
+                _, H, W, _ = t.shape
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
+                check(lib.m355_upsample2x_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
+        return self.raw, self.tensors[self.protos_t]
+
+    # ------------------------------------------------------------------ backward
+    def _gview(self, sl: Slice) -> torch.Tensor:
+        return self.gtensors[sl.t][..., sl.off:sl.off + sl.c]
+
+    def backward(self, d_raw: torch.Tensor, d_protos: torch.Tensor) -> None:
+        """d_raw (B,A,64+nc+32) fp32, d_protos (B,H/4,W/4,32): gradients of the loss w.r.t. forward()'s outputs.
+        Fills ``self.grads`` (fp32, parameter layout)."""
+        B = self.B
+        st = self._stream()
+        for i, t in enumerate(self.tensors):
+            if self.gtensors[i] is None:
+                self.gtensors[i] = torch.zeros_like(t)
+            else:
+                self.gtensors[i].zero_()
+        self.gtensors[self.protos_t].copy_(d_protos.to(torch.float16))
+        for op in reversed(self.ops):
+            kind = op["kind"]
+            if kind == "conv":
+                name, src, dst = op["name"], op["src"], op["dst"]
+                s = self.specs[name]
+                sv = self.saved[name]
+                tin, tout = self.tensors[src.t], self.tensors[dst.t]
+                hi, wi = tin.shape[1:3]
+                ho, wo = tout.shape[1:3]
+                cout, cin = dst.c, src.c
+                if op["res"] is not None:                                   # y = act(bn(z)) + res
+                    self._gview(op["res"]).add_(self._gview(dst))
+                dyp, _, lddy = self._slice_ptr(self.gtensors, dst)
+                if "dz" not in sv:
+                    sv["dz"] = torch.empty_like(sv["z"])
+                    sv["gb"] = torch.empty(2 * cout, device=self.dev)
+                check(lib.m355_bn_train_bwd_launch(sv["z"].data_ptr(), dyp, B * ho * wo, cout, lddy, cout,
+                                                   sv["mean"].data_ptr(), sv["invstd"].data_ptr(),
+                                                   self.params[f"{name}.bn.weight"].data_ptr(),
+                                                   self.params[f"{name}.bn.bias"].data_ptr(), 1, sv["dz"].data_ptr(), cout,
+                                                   sv["gb"].data_ptr(), st))
+                self.grads[f"{name}.bn.bias"].copy_(sv["gb"][:cout])
+                self.grads[f"{name}.bn.weight"].copy_(sv["gb"][cout:])
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                gw = self.grads[f"{name}.conv.weight"]
+                if s.cin == 3:
+                    if "dw8" not in sv:
+                        sv["dw8"] = torch.empty((cout, 3, 3, 8), device=self.dev)
+                    self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, 8, ho, wo, cout, s.k,
+                                       s.stride, s.k // 2, sv["dw8"])
+                    gw.copy_(sv["dw8"][..., :3])
+                else:
+                    self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, cin, ho, wo, cout, s.k,
+                                       s.stride, s.k // 2, gw)
+                    gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
+                    self._conv_launch(sv["dz"].data_ptr(), ho * wo * cout, cout, ho, wo, cout, self.packed[name + ":dgrad"],
+                                      gp, gbs, ldg, hi, wi, cin, s.k, 1, s.k // 2, res_ptr=gp, r_bs=gbs, ldr=ldg,
+                                      tmode=1 if s.stride == 2 else 0)
+            elif kind == "plain":
+                name, src = op["name"], op["src"]
+                s = self.specs[name]
+                h, w = op["hw"]
+                cout, cp = op["cout"], _ceil(op["cout"], 8)
+                lo = op["level_off"]
+                dz = torch.zeros((B, h * w, cp), dtype=torch.float16, device=self.dev)
+                dz[..., :cout] = d_raw[:, lo:lo + h * w, op["ch_off"]:op["ch_off"] + cout]
+                self.grads[f"{name}.bias"].copy_(dz[..., :cout].float().sum((0, 1)))
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                dw = torch.empty((cp, 1, 1, src.c), device=self.dev)
+                self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, dw)
+                self.grads[f"{name}.weight"].copy_(dw[:cout])
+                gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
+                self._conv_launch(dz.data_ptr(), h * w * cp, cp, h, w, cp, self.packed[name + ":dgrad"], gp, gbs, ldg, h, w,
+                                  src.c, 1, 1, 0, res_ptr=gp, r_bs=gbs, ldr=ldg)
+                op["_dz_keepalive"] = (dz, dw)
+            elif kind == "convt":
+                name, src, dst = op["name"], op["src"], op["dst"]
+                tin = self.tensors[src.t]
+                h, w = tin.shape[1:3]
+                cin, cout = src.c, dst.c
+                gy = self.gtensors[dst.t]                                   # (B, 2h, 2w, cout) contiguous, own tensor
+                self.grads[f"{name}.bias"].copy_(gy.float().sum((0, 1, 2)))
+                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+                # wgrad of the equivalent 2x2 / stride-2 conv (dY -> X): "dz" = X, "x" = dY -> [cin][(dy,dx),co]
+                dw = torch.empty((cin, 2, 2, cout), device=self.dev)
+                self._wgrad_launch(xp, ldx, xbs, gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, h, w, cin, 2, 2, 0, dw)
+                self.grads[f"{name}.weight"].copy_(dw.permute(0, 3, 1, 2))
+                gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
+                self._conv_launch(gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, self.packed[name + ":dgrad"], gp,
+                                  gbs, ldg, h, w, cin, 2, 2, 0, res_ptr=gp, r_bs=gbs, ldr=ldg)
+                op["_dw_keepalive"] = dw
+            elif kind == "pool":                                           # SPPF: y1 = mp(a), y2 = mp(y1), y3 = mp(y2)
+                src, dst = op["src"], op["dst"]
+                c = src.c
+                a = self.tensors[src.t][..., src.off:src.off + c].permute(0, 3, 1, 2).float().requires_grad_(True)
+                y1 = F.max_pool2d(a, 5, 1, 2)
+                y2 = F.max_pool2d(y1, 5, 1, 2)
+                y3 = F.max_pool2d(y2, 5, 1, 2)
+                g = self.gtensors[dst.t][..., dst.off:dst.off + 3 * c].permute(0, 3, 1, 2).float()
+                (ga,) = torch.autograd.grad((y1, y2, y3), a, (g[:, :c], g[:, c:2 * c], g[:, 2 * c:]))
+                self._gview(src).add_(ga.permute(0, 2, 3, 1).half())
+            elif kind == "up":
+                src, dst = op["src"], op["dst"]
+                g = self._gview(dst)
+                Bq, H2, W2, c = g.shape
+                self._gview(src).add_(g.reshape(Bq, H2 // 2, 2, W2 // 2, 2, c).float().sum((2, 4)).half())
