@@ -1,0 +1,102 @@
+"""Product loss module (defectdetection_viaobjectdetection_amd/loss.py) against the training oracle on the same
+seeded head outputs and labels: loss value, the four loss items and the gradients w.r.t. the head outputs.  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import yolov8_seg_train_oracle as tro
+from defectdetection_viaobjectdetection_amd import loss as L
+
+
+def _case(seed, B, nc, imgsz, n_inst, empty_image=False):
+    g = torch.Generator().manual_seed(seed)
+    H, W = imgsz
+    hw = [(H // s, W // s) for s in (8, 16, 32)]
+    A = sum(h * w for h, w in hw)
+    mh, mw = H // 4, W // 4
+    raw = torch.randn(B, A, 64 + nc + 32, generator=g)
+    raw[..., 64:64 + nc] -= 2.0
+    protos = torch.randn(B, mh, mw, 32, generator=g)
+    bidx, cls, boxes = [], [], []
+    masks = torch.zeros(B, mh, mw)
+    for b in range(B):
+        if empty_image and b == 0:
+            continue
+        items = []
+        for i in range(n_inst):
+            cx, cy = torch.rand(2, generator=g).tolist()
+            w, h = (0.1 + 0.4 * torch.rand(2, generator=g)).tolist()
+            cx = min(max(cx, w / 2 + 0.01), 1 - w / 2 - 0.01)
+            cy = min(max(cy, h / 2 + 0.01), 1 - h / 2 - 0.01)
+            items.append((w * h, cx, cy, w, h, int(torch.randint(0, nc, (1,), generator=g))))
+        items.sort(reverse=True)
+        for i, (_, cx, cy, w, h, c) in enumerate(items):
+            bidx.append(b); cls.append(c); boxes.append([cx, cy, w, h])
+            x1, x2 = int((cx - w / 2) * mw), int((cx + w / 2) * mw)
+            y1, y2 = int((cy - h / 2) * mh), int((cy + h / 2) * mh)
+            masks[b, y1:y2 + 1, x1:x2 + 1] = i + 1
+    batch = {"batch_idx": torch.tensor(bidx, dtype=torch.float32), "cls": torch.tensor(cls, dtype=torch.float32).view(-1, 1),
+             "bboxes": torch.tensor(boxes, dtype=torch.float32).view(-1, 4), "masks": masks}
+    return raw, protos, batch, hw
+
+
+def _oracle(raw, protos, batch, hw, nc, imgsz):
+    B = raw.shape[0]
+    raw = raw.clone().requires_grad_(True)
+    protos = protos.clone().requires_grad_(True)
+    maps, o = [], 0
+    for h, w in hw:
+        maps.append(raw[:, o:o + h * w, :64 + nc].permute(0, 2, 1).reshape(B, 64 + nc, h, w))
+        o += h * w
+    mc = raw[:, :, 64 + nc:].permute(0, 2, 1)
+    loss, items = tro.segmentation_loss(maps, mc, protos.permute(0, 3, 1, 2), batch, nc, imgsz)
+    loss.backward()
+    return loss.detach(), items, raw.grad, protos.grad
+
+
+@pytest.mark.parametrize("seed,B,nc,imgsz,n_inst,empty", [
+    (0, 2, 1, (64, 64), 2, False),
+    (1, 3, 3, (96, 64), 3, False),
+    (2, 2, 1, (64, 96), 1, True),       # one image without labels
+    (3, 2, 80, (64, 64), 4, False),
+])
+def test_loss_matches_oracle(seed, B, nc, imgsz, n_inst, empty):
+    raw, protos, batch, hw = _case(seed, B, nc, imgsz, n_inst, empty)
+    lo, io, gro, gpo = _oracle(raw, protos, batch, hw, nc, imgsz)
+    r = raw.clone().requires_grad_(True)
+    p = protos.clone().requires_grad_(True)
+    lp, ip = L.segmentation_loss(r, p, batch, nc, imgsz)
+    lp.backward()
+    assert float(lp) == pytest.approx(float(lo), rel=1e-5)
+    np.testing.assert_allclose(ip.numpy(), io.numpy(), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r.grad.numpy(), gro.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(p.grad.numpy(), gpo.numpy(), rtol=1e-4, atol=1e-6)
+
+
+def test_loss_no_labels_at_all():
+    raw, protos, batch, hw = _case(5, 2, 1, (64, 64), 0)
+    r = raw.clone().requires_grad_(True)
+    p = protos.clone().requires_grad_(True)
+    lp, ip = L.segmentation_loss(r, p, batch, 1, (64, 64))
+    lp.backward()
+    lo, io, gro, gpo = _oracle(raw, protos, batch, hw, 1, (64, 64))
+    assert float(lp) == pytest.approx(float(lo), rel=1e-5)
+    assert float(ip[0]) == 0 and float(ip[1]) == 0 and float(ip[3]) == 0 and float(ip[2]) > 0
+    assert float(p.grad.abs().sum()) == 0
+
+
+def test_assigner_picks_at_most_one_gt_per_anchor():
+    raw, protos, batch, hw = _case(7, 1, 2, (64, 64), 5)
+    anchors, strides = L.anchor_grid((64, 64), "cpu")
+    scores = raw[..., 64:66].sigmoid()
+    ltrb = raw[..., :64].view(1, -1, 4, 16).softmax(3) @ torch.arange(16.0)
+    boxes = torch.cat((anchors - ltrb[..., :2], anchors + ltrb[..., 2:]), -1) * strides
+    b = batch["bboxes"]
+    gt = torch.cat((b[:, :2] - b[:, 2:] / 2, b[:, :2] + b[:, 2:] / 2), 1)[None] * 64
+    tb, ts, fg, idx = L.assign_targets(scores, boxes, anchors * strides, batch["cls"].long().view(1, -1), gt,
+                                       torch.ones(1, gt.shape[1], dtype=torch.bool))
+    assert int(fg.sum()) > 0
+    a = (anchors * strides)[fg[0]]
+    g = gt[0][idx[0][fg[0]]]
+    assert bool(((a > g[:, :2]) & (a < g[:, 2:])).all())      # every positive anchor centre lies inside its GT
+    assert float(ts.max()) <= 1.0 + 1e-5 and float(ts[~fg].abs().sum()) == 0
