@@ -89,9 +89,14 @@ SIGNATURES = {
     "m355_conv_launch": (C.c_int, [C.POINTER(ConvLaunchArgs), _P]),
     "m355_wgrad_launch": (C.c_int, [C.POINTER(WgradLaunchArgs), _P]),
     "m355_bn_train_fwd_launch": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, C.c_int32,
-                                           _P, C.c_int32, _P, _P, _P, _P]),
+                                           _P, C.c_int32, _P, _P, _P, _P, _P, C.c_float, _P]),
     "m355_bn_train_bwd_launch": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32,
                                            _P, C.c_int32, _P, _P]),
+    "m355_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                  C.c_float, C.c_int32, C.c_float, C.c_float, _P]),
+    "m355_sgd_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float,
+                                C.c_float, C.c_float, _P]),
+    "m355_grad_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
     "m355_sppf_pool_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _P]),
     "m355_upsample2x_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

@@ -83,7 +83,13 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
 // train-mode BatchNorm + SiLU (train_kernels.hip)
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
                              float eps, half_t* y, int ldy, const half_t* res, int ldr, float* sums, float* mean_out,
-                             float* invstd_out, int act, hipStream_t s);
+                             float* invstd_out, int act, float* run_mean, float* run_var, float momentum, hipStream_t s);
+int launch_adamw_step(float* p, const float* g, float* m, float* v, float* ema, const unsigned char* group, long n,
+                      float lr, float lr_bias, float beta1, float beta2, float eps, float wd, int step, float grad_mul,
+                      float ema_d, hipStream_t s);
+int launch_sgd_step(float* p, const float* g, float* buf, float* ema, const unsigned char* group, long n, float lr,
+                    float lr_bias, float momentum, int nesterov, float wd, float grad_mul, float ema_d, hipStream_t s);
+int launch_grad_sumsq(const float* g, long n, float* out, hipStream_t s);
 int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int ldz, int lddy, int C, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, float* rsum, half_t* dz,
                              int lddz, int act, hipStream_t s);

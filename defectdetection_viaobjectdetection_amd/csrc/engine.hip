@@ -916,7 +916,7 @@ int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const fl
                            float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream) {
   if (!d_z || !d_gamma || !d_beta || !d_y || !d_mean || !d_invstd || !d_ws) return set_err(M355_ERR_INVALID, "null pointer");
   const int rc = launch_bn_silu_train_fwd((const half_t*)d_z, (long)B * H * W, C, C, d_gamma, d_beta, eps, (half_t*)d_y, C,
-                                          nullptr, 0, d_ws, d_mean, d_invstd, act, (hipStream_t)stream);
+                                          nullptr, 0, d_ws, d_mean, d_invstd, act, nullptr, nullptr, 0.f, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn fwd launch failed: " + std::to_string(rc));
 }
 
@@ -1033,10 +1033,12 @@ int m355_wgrad_launch(const m355_wgrad_args* w, void* stream) {
 
 int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C, const float* gamma, const float* beta,
                              float eps, int32_t act, void* y, int32_t ldy, const void* res, int32_t ldr, float* mean,
-                             float* invstd, float* ws, void* stream) {
+                             float* invstd, float* ws, float* running_mean, float* running_var, float momentum,
+                             void* stream) {
   if (!z || !gamma || !beta || !y || !mean || !invstd || !ws) return set_err(M355_ERR_INVALID, "null pointer");
   const int rc = launch_bn_silu_train_fwd((const half_t*)z, npix, ldz, C, gamma, beta, eps, (half_t*)y, ldy,
-                                          (const half_t*)res, ldr, ws, mean, invstd, act, (hipStream_t)stream);
+                                          (const half_t*)res, ldr, ws, mean, invstd, act, running_mean, running_var, momentum,
+                                          (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn fwd launch failed: " + std::to_string(rc));
 }
 
@@ -1049,6 +1051,21 @@ int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn bwd launch failed: " + std::to_string(rc));
 }
 
+int m355_adamw_step(float* p, const float* g, float* m, float* v, float* ema, const uint8_t* group, int64_t n, float lr,
+                    float lr_bias, float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_mul,
+                    float ema_decay, void* stream) {
+  return m355::launch_adamw_step(p, g, m, v, ema, group, n, lr, lr_bias, beta1, beta2, eps, weight_decay, step, grad_mul,
+                                 ema_decay, (hipStream_t)stream);
+}
+int m355_sgd_step(float* p, const float* g, float* momentum_buf, float* ema, const uint8_t* group, int64_t n, float lr,
+                  float lr_bias, float momentum, int32_t nesterov, float weight_decay, float grad_mul, float ema_decay,
+                  void* stream) {
+  return m355::launch_sgd_step(p, g, momentum_buf, ema, group, n, lr, lr_bias, momentum, nesterov, weight_decay, grad_mul,
+                               ema_decay, (hipStream_t)stream);
+}
+int m355_grad_sumsq(const float* g, int64_t n, float* out, void* stream) {
+  return m355::launch_grad_sumsq(g, n, out, (hipStream_t)stream);
+}
 int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

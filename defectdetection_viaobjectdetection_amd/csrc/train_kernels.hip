@@ -54,7 +54,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t*
                                                                    const float* sums, const float* gamma,
                                                                    const float* beta, float eps, half_t* y, int ldy,
                                                                    const half_t* res, int ldr, float* mean_out,
-                                                                   float* invstd_out, int act) {
+                                                                   float* invstd_out, int act, float* run_mean,
+                                                                   float* run_var, float momentum) {
   const int cg = C / 8;
   const long total = npix * cg;
   const float inv_n = 1.0f / (float)npix;
@@ -76,6 +77,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t*
       if (p == 0 && mean_out) {
         mean_out[c] = m;
         invstd_out[c] = is;
+      }
+      if (p == 0 && run_mean) {  // running statistics: momentum update with the unbiased variance
+        const float n = (float)npix;
+        run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * m;
+        run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.0f, 1.0f));
       }
     }
     *(half8*)(y + p * ldy + g * 8) = o;
@@ -162,6 +168,66 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_bwd_apply_kernel(const hal
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Optimizer step over the flat fp32 parameter buffer: one pass reads p, g, state and the EMA
+// copy and writes them back -- 36 B/param for AdamW, 28 B/param for SGD -- instead of ~10 elementwise passes.
+// group[i]: 0 = conv weights (decayed), 1 = norm weights, 2 = biases (own learning rate during warm-up).
+// grad_mul folds 1/loss_scale and the gradient-clipping coefficient.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_step_kernel(float* p, const float* g, float* m, float* v, float* ema,
+                                                         const unsigned char* group, long n, float lr, float lr_bias,
+                                                         float beta1, float beta2, float eps, float wd, float bc1,
+                                                         float rsqrt_bc2, float grad_mul, float ema_d) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int gr = group[i];
+    const float l = gr == 2 ? lr_bias : lr;
+    const float gi = g[i] * grad_mul;
+    float pi = p[i];
+    if (gr == 0) pi *= 1.0f - l * wd;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    pi -= (l / bc1) * mi / (sqrtf(vi) * rsqrt_bc2 + eps);
+    p[i] = pi; m[i] = mi; v[i] = vi;
+    if (ema) ema[i] = ema_d * ema[i] + (1.0f - ema_d) * pi;
+  }
+}
+
+__global__ __launch_bounds__(256) void sgd_step_kernel(float* p, const float* g, float* buf, float* ema,
+                                                       const unsigned char* group, long n, float lr, float lr_bias,
+                                                       float momentum, int nesterov, float wd, float grad_mul, float ema_d) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int gr = group[i];
+    const float l = gr == 2 ? lr_bias : lr;
+    float pi = p[i];
+    float gi = g[i] * grad_mul;
+    if (gr == 0) gi += wd * pi;
+    const float bi = momentum * buf[i] + gi;
+    gi = nesterov ? gi + momentum * bi : bi;
+    pi -= l * gi;
+    p[i] = pi; buf[i] = bi;
+    if (ema) ema[i] = ema_d * ema[i] + (1.0f - ema_d) * pi;
+  }
+}
+
+// out[0] += sum g^2, out[1] += number of non-finite entries (wave shuffle reduction, one atomic pair per wave)
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long n, float* out) {
+  float s = 0.f, bad = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float x = g[i];
+    if (isfinite(x)) s += x * x; else bad += 1.f;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_down(s, o, 64);
+    bad += __shfl_down(bad, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&out[0], s);
+    if (bad != 0.f) atomicAdd(&out[1], bad);
+  }
+}
+
 int grid_for(long work_items) {
   long b = (work_items + BN_THREADS - 1) / BN_THREADS;
   if (b > 256 * 8) b = 256 * 8;
@@ -174,7 +240,7 @@ int grid_for(long work_items) {
 // sums: device float[2C] zeroed by this call (hipMemsetAsync on the same stream)
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
                              float eps, half_t* y, int ldy, const half_t* res, int ldr, float* sums, float* mean_out,
-                             float* invstd_out, int act, hipStream_t s) {
+                             float* invstd_out, int act, float* run_mean, float* run_var, float momentum, hipStream_t s) {
   if (C % 8 || ldz % 8 || ldy % 8 || C / 8 > BN_THREADS) return -1;
   hipError_t e = hipMemsetAsync(sums, 0, 2 * C * sizeof(float), s);
   if (e != hipSuccess) return (int)e;
@@ -182,7 +248,7 @@ int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const f
   hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
                      BN_THREADS * 16 * sizeof(float), s, z, npix, ldz, C, sums);
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(BN_THREADS), 0, s, z, npix, ldz, C, sums,
-                     gamma, beta, eps, y, ldy, res, ldr, mean_out, invstd_out, act);
+                     gamma, beta, eps, y, ldy, res, ldr, mean_out, invstd_out, act, run_mean, run_var, momentum);
   return (int)hipGetLastError();
 }
 
@@ -198,6 +264,33 @@ int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int l
                      BN_THREADS * 16 * sizeof(float), s, z, dy, npix, ldz, lddy, C, mean, invstd, gamma, beta, rsum, act);
   hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
                      lddy, C, mean, invstd, gamma, beta, rsum, dz, lddz, act);
+  return (int)hipGetLastError();
+}
+
+int launch_adamw_step(float* p, const float* g, float* m, float* v, float* ema, const unsigned char* group, long n,
+                      float lr, float lr_bias, float beta1, float beta2, float eps, float wd, int step, float grad_mul,
+                      float ema_d, hipStream_t s) {
+  if (n <= 0 || step < 1) return -1;
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float rsqrt_bc2 = 1.0f / sqrtf(1.0f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_step_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, m, v, ema, group, n, lr, lr_bias, beta1,
+                     beta2, eps, wd, bc1, rsqrt_bc2, grad_mul, ema_d);
+  return (int)hipGetLastError();
+}
+
+int launch_sgd_step(float* p, const float* g, float* buf, float* ema, const unsigned char* group, long n, float lr,
+                    float lr_bias, float momentum, int nesterov, float wd, float grad_mul, float ema_d, hipStream_t s) {
+  if (n <= 0) return -1;
+  hipLaunchKernelGGL(sgd_step_kernel, dim3(grid_for(n)), dim3(256), 0, s, p, g, buf, ema, group, n, lr, lr_bias, momentum,
+                     nesterov, wd, grad_mul, ema_d);
+  return (int)hipGetLastError();
+}
+
+int launch_grad_sumsq(const float* g, long n, float* out, hipStream_t s) {
+  if (n <= 0) return -1;
+  hipError_t e = hipMemsetAsync(out, 0, 2 * sizeof(float), s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(grad_sumsq_kernel, dim3(grid_for(n)), dim3(256), 0, s, g, n, out);
   return (int)hipGetLastError();
 }
 

@@ -204,5 +204,6 @@ class YOLO:
         return _train(self, data=data, epochs=epochs, imgsz=imgsz, batch=batch, project=project, name=name,
                       device=device, **kwargs)
 
-    def val(self, **kwargs):
-        raise NotImplementedError("validation (SURVEY.md A17) is scheduled with the training rows")
+    def val(self, data: Optional[str] = None, imgsz: Optional[int] = None, batch: int = 16, device=0, **kwargs):
+        from .train import validate as _validate
+        return _validate(self, data=data, imgsz=imgsz, batch=batch, device=device, **kwargs)

@@ -170,14 +170,45 @@ class TrainEngine:
             else:
                 self.params[f"{s.name}.weight"] = sd[f"{s.name}.weight"].float().permute(0, 2, 3, 1).contiguous().to(self.dev)
                 self.params[f"{s.name}.bias"] = sd[f"{s.name}.bias"].float().clone().to(self.dev)
-        for k, v in self.params.items():
-            if "running_" not in k:
-                self.grads[k] = torch.zeros_like(v)
+        self._flatten()
         self.repack()
 
-    def state_dict(self) -> Dict[str, torch.Tensor]:
+    def _flatten(self) -> None:
+        """Re-home parameters, buffers and gradients in flat fp32 buffers (views keep their names and shapes):
+        ``flat_params[:n_train]`` trainable, the tail = BN running statistics; ``flat_grads`` matches the head.
+        One buffer = one optimizer launch and one all-reduce.  ``group`` marks 0 weights / 1 norm weights / 2 biases."""
+        train = [k for k in self.params if "running_" not in k]
+        bufs = [k for k in self.params if "running_" in k]
+        n_train = sum(self.params[k].numel() for k in train)
+        n_all = n_train + sum(self.params[k].numel() for k in bufs)
+        flat = torch.empty(n_all, device=self.dev)
+        self.flat_grads = torch.zeros(n_train, device=self.dev)
+        self.group = torch.empty(n_train, dtype=torch.uint8, device=self.dev)
+        o = 0
+        self.layout: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        for k in train + bufs:
+            v = self.params[k]
+            n = v.numel()
+            self.layout[k] = (o, tuple(v.shape))
+            flat[o:o + n].copy_(v.reshape(-1))
+            self.params[k] = flat[o:o + n].view(v.shape)
+            if o < n_train:
+                self.grads[k] = self.flat_grads[o:o + n].view(v.shape)
+                self.group[o:o + n] = 2 if k.endswith(".bias") else (1 if ".bn." in k else 0)
+            o += n
+        self.flat_params, self.n_train = flat, n_train
+
+    def grad_spans(self) -> Dict[str, Tuple[int, int]]:
+        """{name: (offset, numel)} of the trainable parameters inside ``flat_grads`` (for GradBucketReducer)."""
+        return {k: (o, int(torch.Size(sh).numel())) for k, (o, sh) in self.layout.items() if o < self.n_train}
+
+    def state_dict(self, flat: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        """Upstream-named state dict (OIHW weights, CPU).  ``flat``: read the values from another flat buffer of the
+        same layout (the EMA copy) instead of the live parameters."""
         out = {}
-        for k, v in self.params.items():
+        src = self.params if flat is None else {k: flat[o:o + torch.Size(sh).numel()].view(sh)
+                                                for k, (o, sh) in self.layout.items()}
+        for k, v in src.items():
             name = k.rsplit(".", 1)[0].replace(".conv", "")
             s = self.specs.get(name) or self.specs.get(k.rsplit(".", 2)[0])
             if k.endswith("weight") and v.dim() == 4 and not (s and s.transposed):
@@ -281,15 +312,13 @@ class TrainEngine:
                 rp, ldr = (0, 0)
                 if op["res"] is not None:
                     rp, _, ldr = self._slice_ptr(self.tensors, op["res"])
+                rm = self.params[f"{name}.bn.running_mean"].data_ptr() if update_running_stats else 0
+                rv = self.params[f"{name}.bn.running_var"].data_ptr() if update_running_stats else 0
                 check(lib.m355_bn_train_fwd_launch(sv["z"].data_ptr(), B * ho * wo, cout, cout,
                                                    self.params[f"{name}.bn.weight"].data_ptr(),
                                                    self.params[f"{name}.bn.bias"].data_ptr(), BN_EPS, 1, yp, ldy, rp, ldr,
-                                                   sv["mean"].data_ptr(), sv["invstd"].data_ptr(), sv["ws"].data_ptr(), st))
-                if update_running_stats:
-                    n = B * ho * wo
-                    var = (1.0 / sv["invstd"] ** 2 - BN_EPS).clamp_(min=0) * (n / max(n - 1, 1))
-                    self.params[f"{name}.bn.running_mean"].mul_(1 - BN_MOMENTUM).add_(sv["mean"], alpha=BN_MOMENTUM)
-                    self.params[f"{name}.bn.running_var"].mul_(1 - BN_MOMENTUM).add_(var, alpha=BN_MOMENTUM)
+                                                   sv["mean"].data_ptr(), sv["invstd"].data_ptr(), sv["ws"].data_ptr(),
+                                                   rm, rv, BN_MOMENTUM, st))
             elif kind == "plain":
                 name, src = op["name"], op["src"]
                 tin = self.tensors[src.t]
@@ -330,9 +359,10 @@ class TrainEngine:
     def _gview(self, sl: Slice) -> torch.Tensor:
         return self.gtensors[sl.t][..., sl.off:sl.off + sl.c]
 
-    def backward(self, d_raw: torch.Tensor, d_protos: torch.Tensor) -> None:
+    def backward(self, d_raw: torch.Tensor, d_protos: torch.Tensor, on_ready=None) -> None:
         """d_raw (B,A,64+nc+32) fp32, d_protos (B,H/4,W/4,32): gradients of the loss w.r.t. forward()'s outputs.
-        Fills ``self.grads`` (fp32, parameter layout)."""
+        Fills ``self.grads`` (fp32, parameter layout).  ``on_ready(name)`` is called once the kernels producing that
+        parameter's gradient have been enqueued (GradBucketReducer.mark_ready: the all-reduce is stream-ordered)."""
         B = self.B
         st = self._stream()
         for i, t in enumerate(self.tensors):
@@ -341,7 +371,12 @@ class TrainEngine:
             else:
                 self.gtensors[i].zero_()
         self.gtensors[self.protos_t].copy_(d_protos.to(torch.float16))
+        ready: List[str] = []
         for op in reversed(self.ops):
+            if on_ready is not None:                                        # gradients finished by the previous op
+                for k in ready:
+                    on_ready(k)
+            ready = []
             kind = op["kind"]
             if kind == "conv":
                 name, src, dst = op["name"], op["src"], op["dst"]
@@ -364,6 +399,7 @@ class TrainEngine:
                                                    sv["gb"].data_ptr(), st))
                 self.grads[f"{name}.bn.bias"].copy_(sv["gb"][:cout])
                 self.grads[f"{name}.bn.weight"].copy_(sv["gb"][cout:])
+                ready += [f"{name}.bn.bias", f"{name}.bn.weight", f"{name}.conv.weight"]
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 gw = self.grads[f"{name}.conv.weight"]
                 if s.cin == 3:
@@ -392,6 +428,7 @@ class TrainEngine:
                 dw = torch.empty((cp, 1, 1, src.c), device=self.dev)
                 self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, dw)
                 self.grads[f"{name}.weight"].copy_(dw[:cout])
+                ready += [f"{name}.bias", f"{name}.weight"]
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                 self._conv_launch(dz.data_ptr(), h * w * cp, cp, h, w, cp, self.packed[name + ":dgrad"], gp, gbs, ldg, h, w,
                                   src.c, 1, 1, 0, res_ptr=gp, r_bs=gbs, ldr=ldg)
@@ -408,6 +445,7 @@ class TrainEngine:
                 dw = torch.empty((cin, 2, 2, cout), device=self.dev)
                 self._wgrad_launch(xp, ldx, xbs, gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, h, w, cin, 2, 2, 0, dw)
                 self.grads[f"{name}.weight"].copy_(dw.permute(0, 3, 1, 2))
+                ready += [f"{name}.bias", f"{name}.weight"]
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                 self._conv_launch(gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, self.packed[name + ":dgrad"], gp,
                                   gbs, ldg, h, w, cin, 2, 2, 0, res_ptr=gp, r_bs=gbs, ldr=ldg)
@@ -427,3 +465,6 @@ class TrainEngine:
                 g = self._gview(dst)
                 Bq, H2, W2, c = g.shape
                 self._gview(src).add_(g.reshape(Bq, H2 // 2, 2, W2 // 2, 2, c).float().sum((2, 4)).half())
+        if on_ready is not None:
+            for k in ready:
+                on_ready(k)

@@ -195,10 +195,12 @@ typedef struct {
 } m355_wgrad_args;
 int m355_wgrad_launch(const m355_wgrad_args* a, void* stream);
 
-/* Train-mode BN(+SiLU)(+residual) on slices: y = act(bn(z)) + res. */
+/* Train-mode BN(+SiLU)(+residual) on slices: y = act(bn(z)) + res.  running_mean / running_var (may be NULL) get the
+ * momentum update r = (1 - momentum) * r + momentum * batch_stat (unbiased variance), like torch BatchNorm2d. */
 int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C, const float* gamma, const float* beta,
                              float eps, int32_t act, void* y, int32_t ldy, const void* res, int32_t ldr, float* mean,
-                             float* invstd, float* ws, void* stream);
+                             float* invstd, float* ws, float* running_mean, float* running_var, float momentum,
+                             void* stream);
 int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_t ldz, int32_t lddy, int32_t C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t act,
                              void* dz, int32_t lddz, float* dbeta_dgamma, void* stream);
@@ -206,6 +208,18 @@ int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y
                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* Optimizer step over a flat fp32 parameter buffer (replaces torch.optim.AdamW / SGD + ModelEMA.update reached from
+ * /root/reference/BscanBased/yolo_seg_train.py:12).  group[i]: 0 decayed weights, 1 norm weights, 2 biases (lr_bias).
+ * grad_mul = clip_coef / loss_scale.  ema may be NULL.  step counts from 1 (Adam bias correction). */
+int m355_adamw_step(float* p, const float* g, float* m, float* v, float* ema, const uint8_t* group, int64_t n, float lr,
+                    float lr_bias, float beta1, float beta2, float eps, float weight_decay, int32_t step, float grad_mul,
+                    float ema_decay, void* stream);
+int m355_sgd_step(float* p, const float* g, float* momentum_buf, float* ema, const uint8_t* group, int64_t n, float lr,
+                  float lr_bias, float momentum, int32_t nesterov, float weight_decay, float grad_mul, float ema_decay,
+                  void* stream);
+/* out[0] = sum of squares of the finite entries of g, out[1] = number of non-finite entries (device floats). */
+int m355_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
 
 #ifdef __cplusplus
 }
