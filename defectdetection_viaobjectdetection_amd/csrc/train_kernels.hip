@@ -49,7 +49,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const half_t* z, l
 }
 
 // mean / invstd from the sums (biased variance, like torch batch_norm in training mode), optional
-// running-stat update with momentum (unbiased variance), then y = silu(gamma * (z - mean) * invstd + beta)
+// running-stat update with momentum (unbiased variance), then y = silu(gamma * (z - mean) * invstd + beta).
+// A thread owns one 8-channel group for its whole life (scale / shift live in registers) and walks pixels.
 __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t* z, long npix, int ldz, int C,
                                                                    const float* sums, const float* gamma,
                                                                    const float* beta, float eps, half_t* y, int ldy,
@@ -57,34 +58,58 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t*
                                                                    float* invstd_out, int act, float* run_mean,
                                                                    float* run_var, float momentum) {
   const int cg = C / 8;
-  const long total = npix * cg;
+  const int lanes_px = BN_THREADS / cg;
+  const int cgi = threadIdx.x % cg, pl = threadIdx.x / cg;
+  if (pl >= lanes_px) return;
   const float inv_n = 1.0f / (float)npix;
-  for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * BN_THREADS) {
-    const long p = i / cg;
-    const int g = (int)(i - p * cg);
-    const half8 v = *(const half8*)(z + p * ldz + g * 8);
-    half8 rv = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (res) rv = *(const half8*)(res + p * ldr + g * 8);
-    half8 o;
+  float sc[8], sh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = g * 8 + j;
-      const float m = sums[c] * inv_n;
-      const float var = fmaxf(sums[C + c] * inv_n - m * m, 0.f);
-      const float is = rsqrtf(var + eps);
-      const float u = gamma[c] * ((float)v[j] - m) * is + beta[c];
-      o[j] = (half_t)((act ? u * sigmoid_f(u) : u) + (float)rv[j]);
-      if (p == 0 && mean_out) {
+  for (int j = 0; j < 8; ++j) {
+    const int c = cgi * 8 + j;
+    const float m = sums[c] * inv_n;
+    const float var = fmaxf(sums[C + c] * inv_n - m * m, 0.f);
+    const float is = rsqrtf(var + eps);
+    sc[j] = gamma[c] * is;
+    sh[j] = beta[c] - m * sc[j];
+    if (blockIdx.x == 0 && pl == 0) {
+      if (mean_out) {
         mean_out[c] = m;
         invstd_out[c] = is;
       }
-      if (p == 0 && run_mean) {  // running statistics: momentum update with the unbiased variance
+      if (run_mean) {  // running statistics: momentum update with the unbiased variance
         const float n = (float)npix;
         run_mean[c] = (1.0f - momentum) * run_mean[c] + momentum * m;
         run_var[c] = (1.0f - momentum) * run_var[c] + momentum * var * (n / fmaxf(n - 1.0f, 1.0f));
       }
     }
-    *(half8*)(y + p * ldy + g * 8) = o;
+  }
+  const long stride = (long)gridDim.x * lanes_px;
+  constexpr int U = 4;
+  for (long p0 = (long)blockIdx.x * lanes_px + pl; p0 < npix; p0 += stride * U) {
+    half8 v[U], rv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + u * stride;
+      if (p < npix) {
+        v[u] = *(const half8*)(z + p * ldz + cgi * 8);
+        if (res) rv[u] = *(const half8*)(res + p * ldr + cgi * 8);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + u * stride;
+      if (p < npix) {
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float t = (float)v[u][j] * sc[j] + sh[j];
+          float r = act ? t * sigmoid_f(t) : t;
+          if (res) r += (float)rv[u][j];
+          o[j] = (half_t)r;
+        }
+        *(half8*)(y + p * ldy + cgi * 8) = o;
+      }
+    }
   }
 }
 
@@ -137,37 +162,59 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_bwd_reduce_kernel(const ha
   }
 }
 
-// dz = gamma * invstd * (du - dbeta / N - xhat * dgamma / N)
+// dz = gamma * invstd * (du - dbeta / N - xhat * dgamma / N); same thread-owns-a-channel-group walk as the forward
 __global__ __launch_bounds__(BN_THREADS) void bn_silu_bwd_apply_kernel(const half_t* z, const half_t* dy, long npix,
                                                                        int ldz, int lddy, int C, const float* mean,
                                                                        const float* invstd, const float* gamma,
                                                                        const float* beta, const float* rsum,
                                                                        half_t* dz, int lddz, int act) {
   const int cg = C / 8;
-  const long total = npix * cg;
+  const int lanes_px = BN_THREADS / cg;
+  const int cgi = threadIdx.x % cg, pl = threadIdx.x / cg;
+  if (pl >= lanes_px) return;
   const float inv_n = 1.0f / (float)npix;
-  for (long i = (long)blockIdx.x * BN_THREADS + threadIdx.x; i < total; i += (long)gridDim.x * BN_THREADS) {
-    const long p = i / cg;
-    const int g = (int)(i - p * cg);
-    const half8 v = *(const half8*)(z + p * ldz + g * 8);
-    const half8 d = *(const half8*)(dy + p * lddy + g * 8);
-    half8 o;
+  float m[8], is[8], ga[8], be[8], k1[8], k2[8], k3[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int c = g * 8 + j;
-      const float xh = ((float)v[j] - mean[c]) * invstd[c];
-      float du = (float)d[j];
-      if (act) {
-        const float u = gamma[c] * xh + beta[c];
-        const float sg = sigmoid_f(u);
-        du *= sg * (1.0f + u * (1.0f - sg));
+  for (int j = 0; j < 8; ++j) {
+    const int c = cgi * 8 + j;
+    m[j] = mean[c]; is[j] = invstd[c]; ga[j] = gamma[c]; be[j] = beta[c];
+    k1[j] = ga[j] * is[j];
+    k2[j] = rsum[c] * inv_n;
+    k3[j] = rsum[C + c] * inv_n;
+  }
+  const long stride = (long)gridDim.x * lanes_px;
+  constexpr int U = 4;
+  for (long p0 = (long)blockIdx.x * lanes_px + pl; p0 < npix; p0 += stride * U) {
+    half8 v[U], d[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + u * stride;
+      if (p < npix) {
+        v[u] = *(const half8*)(z + p * ldz + cgi * 8);
+        d[u] = *(const half8*)(dy + p * lddy + cgi * 8);
       }
-      o[j] = (half_t)(gamma[c] * invstd[c] * (du - rsum[c] * inv_n - xh * rsum[C + c] * inv_n));
     }
-    *(half8*)(dz + p * lddz + g * 8) = o;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long p = p0 + u * stride;
+      if (p < npix) {
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = ((float)v[u][j] - m[j]) * is[j];
+          float du = (float)d[u][j];
+          if (act) {
+            const float t = ga[j] * xh + be[j];
+            const float sg = sigmoid_f(t);
+            du *= sg * (1.0f + t * (1.0f - sg));
+          }
+          o[j] = (half_t)(k1[j] * (du - k2[j] - xh * k3[j]));
+        }
+        *(half8*)(dz + p * lddz + cgi * 8) = o;
+      }
+    }
   }
 }
-
 
 // ---------------------------------------------------------------------------------------------------------
 // Optimizer step over the flat fp32 parameter buffer: one pass reads p, g, state and the EMA
@@ -235,6 +282,14 @@ int grid_for(long work_items) {
   return (int)b;
 }
 
+// blocks for the pixel-walking apply kernels: 4 pixels per thread per trip, at most 16 blocks per CU
+int grid_px(long npix, int lanes_px) {
+  long b = (npix + (long)lanes_px * 4 - 1) / ((long)lanes_px * 4);
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 }  // namespace
 
 // sums: device float[2C] zeroed by this call (hipMemsetAsync on the same stream)
@@ -247,7 +302,7 @@ int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const f
   const int lanes_px = BN_THREADS / (C / 8);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_for(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
                      BN_THREADS * 16 * sizeof(float), s, z, npix, ldz, C, sums);
-  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(BN_THREADS), 0, s, z, npix, ldz, C, sums,
+  hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, npix, ldz, C, sums,
                      gamma, beta, eps, y, ldy, res, ldr, mean_out, invstd_out, act, run_mean, run_var, momentum);
   return (int)hipGetLastError();
 }
@@ -262,7 +317,7 @@ int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int l
   const int lanes_px = BN_THREADS / (C / 8);
   hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid_for(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
                      BN_THREADS * 16 * sizeof(float), s, z, dy, npix, ldz, lddy, C, mean, invstd, gamma, beta, rsum, act);
-  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_for(npix * (C / 8))), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
+  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
                      lddy, C, mean, invstd, gamma, beta, rsum, dz, lddz, act);
   return (int)hipGetLastError();
 }

@@ -162,7 +162,7 @@ class TrainEngine:
             if s.has_bn:
                 w = sd[f"{s.name}.conv.weight"].float().permute(0, 2, 3, 1).contiguous()
                 self.params[f"{s.name}.conv.weight"] = w.to(self.dev)
-                for p in ("weight", "bias", "running_mean", "running_var"):
+                for p in ("bias", "weight", "running_mean", "running_var"):      # bias, weight adjacent: = BN-bwd output
                     self.params[f"{s.name}.bn.{p}"] = sd[f"{s.name}.bn.{p}"].float().clone().to(self.dev)
             elif s.transposed:
                 self.params[f"{s.name}.weight"] = sd[f"{s.name}.weight"].float().clone().to(self.dev)  # (cin,cout,2,2)
@@ -391,14 +391,13 @@ class TrainEngine:
                 dyp, _, lddy = self._slice_ptr(self.gtensors, dst)
                 if "dz" not in sv:
                     sv["dz"] = torch.empty_like(sv["z"])
-                    sv["gb"] = torch.empty(2 * cout, device=self.dev)
+                gb = self.grads[f"{name}.bn.bias"]                        # [dbeta | dgamma] land in the flat buffer
+                assert self.grads[f"{name}.bn.weight"].data_ptr() == gb.data_ptr() + 4 * cout
                 check(lib.m355_bn_train_bwd_launch(sv["z"].data_ptr(), dyp, B * ho * wo, cout, lddy, cout,
                                                    sv["mean"].data_ptr(), sv["invstd"].data_ptr(),
                                                    self.params[f"{name}.bn.weight"].data_ptr(),
                                                    self.params[f"{name}.bn.bias"].data_ptr(), 1, sv["dz"].data_ptr(), cout,
-                                                   sv["gb"].data_ptr(), st))
-                self.grads[f"{name}.bn.bias"].copy_(sv["gb"][:cout])
-                self.grads[f"{name}.bn.weight"].copy_(sv["gb"][cout:])
+                                                   gb.data_ptr(), st))
                 ready += [f"{name}.bn.bias", f"{name}.bn.weight", f"{name}.conv.weight"]
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 gw = self.grads[f"{name}.conv.weight"]

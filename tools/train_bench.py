@@ -7,7 +7,8 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from defectdetection_viaobjectdetection_amd._capi import check, lib  # noqa: E402
 from defectdetection_viaobjectdetection_amd.loss import segmentation_loss  # noqa: E402
 from defectdetection_viaobjectdetection_amd.spec import init_state_dict  # noqa: E402
