@@ -42,7 +42,7 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19 };
 
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s);
 // tile heuristic: cout = (virtual) output channels, M = output pixels of the whole batch
@@ -53,7 +53,10 @@ int conv_kpad(int cin, int ksize);
 
 // 3x3 stride-1 halo-tile kernel (conv3x3_halo.hip)
 bool conv3x3_halo_ok(const ConvArgs& a);
-int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // variant 0 auto, 1: 16x16 px / 8 waves, 2: 8x16 px / 4 waves
+int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // variant 0 auto, 1: 16x16 px / 8 waves, 2: 8x16 px / 4 waves, 3: wide
+// 128 ch x 16x16 px, K depth 32 per step (conv3x3_wide.hip)
+bool conv3x3_wide_ok(const ConvArgs& a);
+int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s);
 
 struct StemArgs {
   const uint8_t* x; int B, H, W;     // uint8 NHWC (B,H,W,3)

@@ -60,8 +60,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbase = smem + npatch * PATCH_BYTES;
 
-  unsigned long long st0 = 0, st1 = 0, st2 = 0;
-  if (a.stamps) st0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+  if (a.stamps) {
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,8 +216,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af1[mt], bf1[nt], acc[mt][nt], 0, 0, 0);
     __builtin_amdgcn_sched_barrier(0);
-    if (s + NWB < nsteps) issue_weights(cN, tN, s & (NWB - 1));
-    if (tap < P_IT && chunk + 1 < nchunks) {
+    if (s + NWB < nsteps && !(a.dbg & 2)) issue_weights(cN, tN, s & (NWB - 1));  // dbg: timing ablations only
+    if (tap < P_IT && chunk + 1 < nchunks && !(a.dbg & 1)) {
 #pragma unroll
       for (int i = 0; i < P_IT; ++i)
         if (i == tap) issue_patch_piece(chunk + 1, i);
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
       }
 #pragma unroll
       for (int j = 0; j < GW; ++j) v[j] += a.bias[ch0 + j];
-      if (a.act) {
+      if (a.act && !(a.dbg & 4)) {
 #pragma unroll
         for (int j = 0; j < GW; ++j) v[j] = silu_f(v[j]);
       }
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
         }
       }
       half_t* yp = (half_t*)a.y + (long)b * a.y_bstride + pix * a.ldy + ch0;
+      if ((a.dbg & 8) && v[0] != 123.f) continue;  // dbg: no stores
       if (GW == 8) {
         half8 o;
 #pragma unroll
@@ -293,8 +297,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
   if (a.stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-    unsigned long long* o = a.stamps + (long)blockIdx.x * 4;
-    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3;
+    unsigned long long* o = a.stamps + (long)blockIdx.x * 8;  // [4..5]: 100 MHz realtime -> in-kernel clock
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -334,6 +338,7 @@ bool conv3x3_halo_ok(const ConvArgs& a) {
 // variant: 0 = auto, 1 = 8 waves / 16x16 px, 2 = 4 waves / 8x16 px
 int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s) {
   if (!conv3x3_halo_ok(a)) return -1;
+  if (variant == 3 || (variant == 0 && conv3x3_wide_ok(a) && !getenv("M355_NO_WIDE"))) return launch_conv3x3_wide(a, s);
   if (variant == 0) {
     const char* ev = getenv("M355_HALO_VARIANT");
     variant = ev ? atoi(ev) : 2;  // measured: the 4-wave variant (two blocks per CU) wins on every layer

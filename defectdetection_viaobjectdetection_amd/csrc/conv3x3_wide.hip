@@ -1,0 +1,294 @@
+// 3x3 / stride-1 / pad-1 NHWC fp16 convolution, WIDE halo tile: 128 channels x (16 x 16) pixels per workgroup,
+// four waves, each owning 64 channels x 8 image rows (MT=4 x NT=8 MFMA tiles, 128 fp32 accumulators per lane).
+//
+// Why a third conv kernel.  Stamps on conv3x3_halo (128 ch x 8x16 px, tools/stamps_halo.py, profiles/r01_*):
+// of a block's 45 k cycles 12 % are prologue and 23 % epilogue; in the loop the 2 x 9216 MFMA cycles per SIMD are
+// 64 % of the wall, and switching the in-loop LDS-DMA off brings that to 84 % -- every 1 KiB DMA piece costs the
+// issuing wave 100+ cycles next to MFMAs, and each step streams 16 KiB of weights for 32 MFMAs per wave.
+// This kernel doubles the pixels per weight byte and halves the K depth per step (32 instead of 64 channels):
+//   per step and wave: 32 MFMAs again, but 2 weight pieces + <=1 patch piece (was 4 + 1), 12 ds_read_b128 (was 16);
+//   per block: 36 instead of 18 steps behind one prologue / epilogue (Cin = 128).
+// LDS (77.5 KiB, two blocks per CU): two patch buffers of 18 rows x 20 px x 64 B (px 18, 19 are padding: a row
+// pitch of 20 makes the swizzle of image row nt+1 the complement of row nt, so the eight B-fragment reads of a
+// tap share two address registers and use the instruction's immediate offset), a 4-deep ring of 8 KiB weight
+// stages, 512 B of bias.  Rows are 64 B = four 16-byte chunks; chunk c of row r lives in slot c ^ (2 * ((r >> 2) & 1)):
+// conflict-free for ds_read_b128 at every row offset (brute-forced over the four 16-lane service groups).
+//
+// Pipeline (one barrier per step, mid-step; A fragments double-buffered, B fragments single-buffered in halves):
+//   P1(s): 8 MFMA (rows 0-1) | ds_read B rows 4-7 of step s | 8 MFMA (rows 2-3)
+//   wait : stage s+1 landed (counted vmcnt), reads landed, s_barrier
+//   P2(s): 8 MFMA (rows 4-5) | LDS-DMA weights of step s+4 (+ one patch piece of the next chunk),
+//          ds_read A(s+1), B rows 0-3 of step s+1 | 8 MFMA (rows 6-7)
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace m355 {
+namespace {
+
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+__device__ __forceinline__ void glds4(const void* gsrc, void* lds_dst) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                   (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
+}
+
+__device__ __forceinline__ float silu_f(float v) {
+  float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+  return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+constexpr int TS = 16, TH = 16;       // output tile
+constexpr int PP = 20;                // patch row pitch in pixels (18 used)
+constexpr int PH = TH + 2;
+constexpr int PROWS = PH * PP;        // 360 LDS rows per patch buffer
+constexpr int ROWB = 64;              // LDS row = 32 halves
+constexpr int PATCH_BYTES = PROWS * ROWB;          // 23040
+constexpr int PPIECES = (PROWS + 15) / 16;         // 23 DMA pieces of 16 rows
+constexpr int P_IT = (PPIECES + 3) / 4;            // 6 per wave
+constexpr int BCH = 128;
+constexpr int WBUF = BCH * ROWB;                   // 8192
+constexpr int NWB = 4;
+constexpr int W_IT = BCH / (4 * 16);               // 2 weight pieces per wave per step
+constexpr int MT = 4, NT = 8;
+constexpr int LDS_BYTES = 2 * PATCH_BYTES + NWB * WBUF + BCH * 4;
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, int tiles_x, int tiles_y, int nchunks) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* const wbase = smem + 2 * PATCH_BYTES;
+  float* const sbias = (float*)(wbase + NWB * WBUF);
+
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+  if (a.stamps) {
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lrow = lane >> 2;                         // row inside a 16-row DMA piece
+  const int lslot = lane & 3;                         // 16-byte slot inside the row
+
+  // ---- block -> tile (XCD-aware: blocks b, b+8, ... share an L2; channel tiles fastest, then x, y, image)
+  const int tiles_ch = (a.Cout + BCH - 1) / BCH;
+  const int nwg = gridDim.x;
+  int L;
+  {
+    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+  }
+  const int tile_ch = L % tiles_ch;
+  int rest = L / tiles_ch;
+  const int tx = rest % tiles_x;
+  rest /= tiles_x;
+  const int ty = rest % tiles_y;
+  const int b = rest / tiles_y;
+  const int ch_base = tile_ch * BCH;
+  const int y0 = ty * TH, x0 = tx * TS;
+  const int H = a.Hi, W = a.Wi;
+  const half_t* const xb = a.x + (long)b * a.x_bstride;
+
+  // ---- patch loader: this wave owns pieces j = wave + 4*i; lane = (LDS row 16j + lane/4, slot lane%4)
+  int poff[P_IT];
+  unsigned pok = 0;
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) {
+    const int j = wave + 4 * i;
+    const int p = 16 * j + lrow;                       // LDS row = patch pixel index (pitch 20)
+    const int py = p / PP, px = p - py * PP;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool in_patch = p < PROWS && px < PH;        // PH == 18 == used patch width
+    const bool ok = in_patch && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const int cc = lslot ^ (((p >> 2) & 1) << 1);      // source chunk that belongs in this slot
+    poff[i] = (iy * W + ix) * a.ldx + cc * 8;
+    if (ok) pok |= 1u << i;
+    if (p < PROWS && !ok) {                            // border / padding slot: stays zero for every chunk
+      const float4v z = {0.f, 0.f, 0.f, 0.f};
+      *(float4v*)(smem + p * ROWB + lslot * 16) = z;
+      *(float4v*)(smem + PATCH_BYTES + p * ROWB + lslot * 16) = z;
+    }
+  }
+  auto issue_patch_piece = [&](int chunk, int i) __attribute__((always_inline)) {
+    if ((pok >> i) & 1u) glds16(xb + poff[i] + chunk * 32, smem + (chunk & 1) * PATCH_BYTES + (wave + 4 * i) * 1024);
+  };
+
+  // ---- weight loader: LDS row R (MFMA-tile order) <- permuted source channel so that a lane ends up with
+  // 8 consecutive output channels (see conv_igemm.hip): R = blk*64 + mt*16 + r
+  const half_t* wrow[W_IT];
+#pragma unroll
+  for (int i = 0; i < W_IT; ++i) {
+    const int R = i * 64 + wave * 16 + lrow;
+    const int blk = R >> 6, Rl = R & 63;
+    const int mt = Rl >> 4, r = Rl & 15;
+    const int chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
+    const int cc = lslot ^ (((R >> 2) & 1) << 1);
+    wrow[i] = a.w + (long)(ch_base + blk * 64 + chl) * a.Kpad + cc * 8;
+  }
+  auto issue_weights = [&](int chunk, int tap, int buf) __attribute__((always_inline)) {
+    const int koff = tap * a.Cin + chunk * 32;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) glds16(wrow[i] + koff, wbase + buf * WBUF + (i * 64 + wave * 16) * ROWB);
+  };
+
+  // ---- fragment addressing
+  const int wch = wave >> 1, wpx = wave & 1;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int aoff = (wch * 64 + l15) * ROWB + ((g ^ (((l15 >> 2) & 1) << 1)) << 4);   // + mt * 1024 (immediate)
+  const int pb = (wpx * NT) * PP + l15;                                                // patch row of (image row 0, x = l15)
+  const int g16 = g << 4;
+  // byte address of the B fragment of image row 0 at (chunk, tap); odd rows use addr ^ 32; row nt adds nt * 1280
+  auto baddr = [&](int chunk, int tap) __attribute__((always_inline)) -> int {
+    const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
+    const int p = pb + kh * PP + kw;
+    return (chunk & 1) * PATCH_BYTES + (p << 6) + (g16 ^ ((p & 4) << 3));
+  };
+
+  float4v acc[MT][NT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+  half8 af0[MT], af1[MT], bf[NT];
+
+  // ---- prologue: bias (oldest DMA, so every counted wait covers it), patch of chunk 0, weights of steps
+  // 0..NWB-1 (all taps of chunk 0: NWB <= 9)
+  if (wave < 2) glds4(a.bias + ch_base + wave * 64 + lane, sbias + wave * 64);
+#pragma unroll
+  for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, i);
+#pragma unroll
+  for (int i = 0; i < NWB; ++i) issue_weights(0, i, i);
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 1) * W_IT) : "memory");  // patch 0 + stage 0 landed
+  __builtin_amdgcn_s_barrier();
+  int be = baddr(0, 0);
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(wbase + aoff + mt * 1024);
+#pragma unroll
+  for (int nt = 0; nt < NT / 2; ++nt) bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));
+
+  if (a.stamps) st1 = __builtin_amdgcn_s_memtime();
+  const int nsteps = nchunks * 9;   // even: nchunks = Cin / 32 with Cin a multiple of 64
+  int chunk = 0, tap = 0;           // of step s
+
+  // one pipeline step; AC = A fragments of this step, AN = A fragments to load for the next one
+#define M355_WIDE_STEP(AC, AN)                                                                                  \
+  {                                                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)           \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int nt = NT / 2; nt < NT; ++nt)                                                       \
+        bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 2; nt < 4; ++nt)           \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (s + NWB - 1 < nsteps)                                                                                    \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 2) * W_IT) : "memory");                         \
+    else                                                                                                         \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    int c1 = chunk, t1 = tap + 1;                                                                                \
+    if (t1 == 9) { t1 = 0; ++c1; }                                                                               \
+    int cN = chunk, tN = tap + NWB;                                                                              \
+    if (tN >= 9) { tN -= 9; ++cN; }                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 4; nt < 6; ++nt)           \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    if (s + NWB < nsteps && !(a.dbg & 2)) issue_weights(cN, tN, s & (NWB - 1));                                  \
+    if (tap < P_IT && chunk + 1 < nchunks && !(a.dbg & 1)) {                                                     \
+      _Pragma("unroll") for (int i = 0; i < P_IT; ++i) if (i == tap) issue_patch_piece(chunk + 1, i);            \
+    }                                                                                                            \
+    be = baddr(c1, t1);                                                                                          \
+    {                                                                                                            \
+      const char* wn = wbase + ((s + 1) & (NWB - 1)) * WBUF + aoff;                                              \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) AN[mt] = *(const half8*)(wn + mt * 1024);                \
+    }                                                                                                            \
+    _Pragma("unroll") for (int nt = 0; nt < NT / 2; ++nt)                                                        \
+        bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 6; nt < 8; ++nt)           \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
+    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    chunk = c1;                                                                                                  \
+    tap = t1;                                                                                                    \
+    ++s;                                                                                                         \
+  }
+
+  for (int s = 0; s < nsteps;) {
+    M355_WIDE_STEP(af0, af1)
+    M355_WIDE_STEP(af1, af0)
+  }
+#undef M355_WIDE_STEP
+
+  if (a.stamps) st2 = __builtin_amdgcn_s_memtime();
+  // ---- epilogue (bias from LDS, SiLU, residual, fp16 pack, 16-byte stores at a channel offset)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int iy = y0 + wpx * NT + nt, ix = x0 + l15;
+    if (iy >= H || ix >= W) continue;
+    const long pix = (long)iy * W + ix;
+#pragma unroll
+    for (int sg = 0; sg < MT / 2; ++sg) {
+      const int chl = wch * 64 + sg * 32 + g * 8;
+      const int ch0 = ch_base + chl;
+      if (ch0 >= a.Cout) continue;
+      const float4v b0 = *(const float4v*)(sbias + chl), b1 = *(const float4v*)(sbias + chl + 4);
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[2 * sg][nt][j] + b0[j];
+        v[4 + j] = acc[2 * sg + 1][nt][j] + b1[j];
+      }
+      if (a.act && !(a.dbg & 4)) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+      }
+      if (a.res) {
+        const half8 rv = *(const half8*)(a.res + (long)b * a.r_bstride + pix * a.ldr + ch0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+      }
+      if ((a.dbg & 8) && v[0] != 123.f) continue;  // dbg: no stores
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+      *(half8*)((half_t*)a.y + (long)b * a.y_bstride + pix * a.ldy + ch0) = o;
+    }
+  }
+  if (a.stamps && tid == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+    unsigned long long* o = a.stamps + (long)blockIdx.x * 8;
+    o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+  }
+}
+
+}  // namespace
+
+// Eligibility: as conv3x3_halo_ok, plus Cout >= 128 and at most 30 % of the computed pixels wasted by 16 x 16 tiles.
+bool conv3x3_wide_ok(const ConvArgs& a) {
+  if (!conv3x3_halo_ok(a) || a.Cout < 128) return false;
+  const long covered = (long)((a.Hi + TH - 1) / TH) * TH * ((a.Wi + TS - 1) / TS) * TS;
+  return covered * 10 <= (long)a.Hi * a.Wi * 13;
+}
+
+int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s) {
+  if (!conv3x3_wide_ok(a)) return -1;
+  const int tiles_x = (a.Wi + TS - 1) / TS, tiles_y = (a.Hi + TH - 1) / TH;
+  const int tiles_ch = (a.Cout + BCH - 1) / BCH;
+  const int B = a.M / (a.Ho * a.Wo);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(B * tiles_y * tiles_x * tiles_ch), dim3(256), LDS_BYTES, s, a, tiles_x,
+                     tiles_y, a.Cin / 32);
+  return (int)hipGetLastError();
+}
+
+}  // namespace m355

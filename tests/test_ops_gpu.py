@@ -62,6 +62,12 @@ CONV_CASES = [
     (2, 32, 32, 128, 128, 3, 1, 1, True, 18),
     (2, 72, 56, 64, 64, 3, 1, 1, True, 18),
     (1, 80, 80, 128, 224, 3, 1, 1, False, 18),
+    # wide halo kernel (19): 128 ch x 16x16 px, 32-deep K steps
+    (2, 32, 32, 128, 128, 3, 1, 1, True, 19),       # 4 chunks, residual
+    (1, 80, 80, 128, 224, 3, 1, 1, False, 19),      # ragged channel tile
+    (2, 72, 56, 64, 128, 3, 1, 1, True, 19),        # 2 chunks, partial spatial tiles
+    (1, 160, 160, 128, 128, 3, 1, 1, False, 19),
+    (3, 48, 32, 192, 256, 3, 1, 0, False, 19),      # 6 chunks, two channel tiles, no act
 ]
 
 

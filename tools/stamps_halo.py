@@ -1,20 +1,27 @@
+"""In-kernel s_memtime / s_memrealtime stamps of the halo conv: prologue / main loop / epilogue cycles per block,
+in-kernel clock, MFMA-cycle share of the main loop.  Usage: python tools/stamps_halo.py [tile] [dbg]"""
 import ctypes as C, sys, os, torch, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["M355_STAMPS"] = "/tmp/stamps.bin"
 from defectdetection_viaobjectdetection_amd import _capi
-P=lambda t: C.c_void_p(0 if t is None else t.data_ptr())
-def run(B,H,W,cin,cout,k,tile):
-    x=torch.randn(B,H,W,cin,device='cuda').half()
-    w=torch.randn(cout,cin,k,k)*0.05; b=torch.zeros(cout)
-    y=torch.empty(B,H,W,cout,device='cuda',dtype=torch.float16)
+P = lambda t: C.c_void_p(0 if t is None else t.data_ptr())
+tile = int(sys.argv[1]) if len(sys.argv) > 1 else 18
+dbg = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+def run(B, H, W, cin, cout, k, mfma_per_wave):
+    x = torch.randn(B, H, W, cin, device='cuda').half()
+    w = torch.randn(cout, cin, k, k) * 0.05; b = torch.zeros(cout)
+    y = torch.empty(B, H, W, cout, device='cuda', dtype=torch.float16)
     for _ in range(2):
-        _capi.check(_capi.lib.m355_conv2d_fwd(P(x),B,H,W,cin,P(w),P(b),cout,k,1,1,P(None),P(y),0,tile,C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    s=np.fromfile("/tmp/stamps.bin",dtype=np.uint64).reshape(-1,4)
-    s=s[s[:,0]>0].astype(np.int64)
-    t0=s[:,0].min()
-    pro=(s[:,1]-s[:,0]); main=(s[:,2]-s[:,1]); epi=(s[:,3]-s[:,2]); tot=(s[:,3]-s[:,0])
-    span=(s[:,3].max()-t0)
-    print(f"{(B,H,W,cin,cout)} blocks {len(s)} span {span/100:.1f}us(100MHz ticks?) prologue med {np.median(pro)} main med {np.median(main)} epi med {np.median(epi)} total med {np.median(tot)}; sum tot/span/256 = {tot.sum()/span/256:.2f} blocks per CU concurrently")
-run(32,160,160,128,128,3,16)
-run(32,80,80,64,64,3,16)
-run(32,80,80,128,224,3,16)
+        _capi.check(_capi.lib.m355_conv2d_fwd(P(x), B, H, W, cin, P(w), P(b), cout, k, 1, 1, P(None), P(y), 0, tile | (dbg << 8),
+                                              C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    s = np.fromfile("/tmp/stamps.bin", dtype=np.uint64).reshape(-1, 8)
+    s = s[s[:, 0] > 0].astype(np.int64)
+    pro = s[:, 1] - s[:, 0]; main = s[:, 2] - s[:, 1]; epi = s[:, 3] - s[:, 2]; tot = s[:, 3] - s[:, 0]
+    rt = (s[:, 5] - s[:, 4]).clip(1)
+    clk = np.median(tot / rt) * 100e6
+    span_rt = (s[:, 5].max() - s[:, 4].min()) / 100e6
+    print(f"{(B, H, W, cin, cout)} tile {tile} dbg {dbg}: blocks {len(s)} kernel span {span_rt * 1e6:.1f} us, in-kernel clock {clk / 1e9:.2f} GHz")
+    print(f"   cycles med: prologue {np.median(pro):.0f} main {np.median(main):.0f} epilogue {np.median(epi):.0f} total {np.median(tot):.0f};"
+          f" MFMA cycles/wave {mfma_per_wave * 16} -> x2 waves/SIMD = {2 * mfma_per_wave * 16 / np.median(main):.2f} of the main loop")
+run(32, 160, 160, 128, 128, 3, 18 * 32)
+run(32, 40, 40, 128, 128, 3, 18 * 32)
