@@ -41,6 +41,10 @@ __device__ __forceinline__ float silu_f(float v) {
   return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// s_waitcnt immediate (gfx9 encoding): vmcnt(n) lgkmcnt(0), expcnt untouched.  The builtin (unlike inline asm) is
+// visible to the compiler's own wait-count insertion, which then does not re-wait for LDS reads issued before it.
+#define WAITCNT_VM_LGKM0(n) ((((n) & 0xf) | (((n) >> 4) << 14) | (7 << 4)))
+
 constexpr int TS = 16, TH = 16;       // output tile
 constexpr int PP = 20;                // patch row pitch in pixels (18 used)
 constexpr int PH = TH + 2;
@@ -54,14 +58,15 @@ constexpr int WBUF = BCH * ROWB;                   // 8192
 constexpr int NWB = 4;
 constexpr int W_IT = BCH / (4 * 16);               // 2 weight pieces per wave per step
 constexpr int MT = 4, NT = 8;
-constexpr int LDS_BYTES = 2 * PATCH_BYTES + NWB * WBUF + BCH * 4;
+constexpr int LDS_BYTES = 2 * PATCH_BYTES + NWB * WBUF + 2 * BCH * 4;
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, int tiles_x, int tiles_y, int nchunks) {
+__global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, int tiles_x, int tiles_y, int nchunks,
+                                                              int ntiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbase = smem + 2 * PATCH_BYTES;
-  float* const sbias = (float*)(wbase + NWB * WBUF);
+  float* const sbias = (float*)(wbase + NWB * WBUF);   // two buffers of BCH floats (tile parity)
 
-  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0, sa = 0, sb = 0, sc = 0, sd = 0;
   if (a.stamps) {
     st0 = __builtin_amdgcn_s_memtime();
     rt0 = __builtin_amdgcn_s_memrealtime();
@@ -71,69 +76,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lrow = lane >> 2;                         // row inside a 16-row DMA piece
   const int lslot = lane & 3;                         // 16-byte slot inside the row
-
-  // ---- block -> tile (XCD-aware: blocks b, b+8, ... share an L2; channel tiles fastest, then x, y, image)
-  const int tiles_ch = (a.Cout + BCH - 1) / BCH;
-  const int nwg = gridDim.x;
-  int L;
-  {
-    const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
-    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-  }
-  const int tile_ch = L % tiles_ch;
-  int rest = L / tiles_ch;
-  const int tx = rest % tiles_x;
-  rest /= tiles_x;
-  const int ty = rest % tiles_y;
-  const int b = rest / tiles_y;
-  const int ch_base = tile_ch * BCH;
-  const int y0 = ty * TH, x0 = tx * TS;
   const int H = a.Hi, W = a.Wi;
-  const half_t* const xb = a.x + (long)b * a.x_bstride;
+  const int tiles_ch = (a.Cout + BCH - 1) / BCH;
 
-  // ---- patch loader: this wave owns pieces j = wave + 4*i; lane = (LDS row 16j + lane/4, slot lane%4)
-  int poff[P_IT];
-  unsigned pok = 0;
-#pragma unroll
-  for (int i = 0; i < P_IT; ++i) {
-    const int j = wave + 4 * i;
-    const int p = 16 * j + lrow;                       // LDS row = patch pixel index (pitch 20)
-    const int py = p / PP, px = p - py * PP;
-    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-    const bool in_patch = p < PROWS && px < PH;        // PH == 18 == used patch width
-    const bool ok = in_patch && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-    const int cc = lslot ^ (((p >> 2) & 1) << 1);      // source chunk that belongs in this slot
-    poff[i] = (iy * W + ix) * a.ldx + cc * 8;
-    if (ok) pok |= 1u << i;
-    if (p < PROWS && !ok) {                            // border / padding slot: stays zero for every chunk
-      const float4v z = {0.f, 0.f, 0.f, 0.f};
-      *(float4v*)(smem + p * ROWB + lslot * 16) = z;
-      *(float4v*)(smem + PATCH_BYTES + p * ROWB + lslot * 16) = z;
-    }
-  }
-  auto issue_patch_piece = [&](int chunk, int i) __attribute__((always_inline)) {
-    if ((pok >> i) & 1u) glds16(xb + poff[i] + chunk * 32, smem + (chunk & 1) * PATCH_BYTES + (wave + 4 * i) * 1024);
-  };
-
-  // ---- weight loader: LDS row R (MFMA-tile order) <- permuted source channel so that a lane ends up with
-  // 8 consecutive output channels (see conv_igemm.hip): R = blk*64 + mt*16 + r
-  const half_t* wrow[W_IT];
-#pragma unroll
-  for (int i = 0; i < W_IT; ++i) {
-    const int R = i * 64 + wave * 16 + lrow;
-    const int blk = R >> 6, Rl = R & 63;
-    const int mt = Rl >> 4, r = Rl & 15;
-    const int chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
-    const int cc = lslot ^ (((R >> 2) & 1) << 1);
-    wrow[i] = a.w + (long)(ch_base + blk * 64 + chl) * a.Kpad + cc * 8;
-  }
-  auto issue_weights = [&](int chunk, int tap, int buf) __attribute__((always_inline)) {
-    const int koff = tap * a.Cin + chunk * 32;
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) glds16(wrow[i] + koff, wbase + buf * WBUF + (i * 64 + wave * 16) * ROWB);
-  };
-
-  // ---- fragment addressing
+  // ---- fragment addressing (tile independent)
   const int wch = wave >> 1, wpx = wave & 1;
   const int l15 = lane & 15, g = lane >> 4;
   const int aoff = (wch * 64 + l15) * ROWB + ((g ^ (((l15 >> 2) & 1) << 1)) << 4);   // + mt * 1024 (immediate)
@@ -146,44 +92,169 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     return (chunk & 1) * PATCH_BYTES + (p << 6) + (g16 ^ ((p & 4) << 3));
   };
 
+  // ---- persistent walk over tiles: virtual block vb = blockIdx.x + k * gridDim.x (gridDim.x is a multiple of 8 or
+  // equals ntiles, so vb & 7 is this block's XCD for every k).  XCD-aware order: the virtual blocks of one XCD cover
+  // a contiguous range of tiles; channel tiles fastest, then x, y, image.
+  int tb, ty0, tx0, tch;   // image, first row, first column, first channel of the CURRENT tile
+  auto decode = [&](int vb) __attribute__((always_inline)) {
+    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    const int tile_ch = L % tiles_ch;
+    int rest = L / tiles_ch;
+    const int tx = rest % tiles_x;
+    rest /= tiles_x;
+    const int ty = rest % tiles_y;
+    tb = rest / tiles_y;
+    tch = tile_ch * BCH;
+    ty0 = ty * TH;
+    tx0 = tx * TS;
+  };
+
+  // ---- per-tile loader state
+  int poff[P_IT];
+  unsigned pok;
+  const half_t* xb;
+  const half_t* wrow[W_IT];
+  auto setup = [&]() __attribute__((always_inline)) {
+    xb = a.x + (long)tb * a.x_bstride;
+    pok = 0;
+    // patch: this wave owns pieces j = wave + 4*i; lane = (LDS row 16j + lane/4, slot lane%4)
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) {
+      const int j = wave + 4 * i;
+      const int p = 16 * j + lrow;                       // LDS row = patch pixel index (pitch 20)
+      const int py = p / PP, px = p - py * PP;
+      const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+      const bool in_patch = p < PROWS && px < PH;        // PH == 18 == used patch width
+      const bool ok = in_patch && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int cc = lslot ^ (((p >> 2) & 1) << 1);      // source chunk that belongs in this slot
+      poff[i] = (iy * W + ix) * a.ldx + cc * 8;
+      if (ok) pok |= 1u << i;
+      if (p < PROWS && !ok) {                            // border / padding slot: stays zero for every chunk
+        const float4v z = {0.f, 0.f, 0.f, 0.f};
+        *(float4v*)(smem + p * ROWB + lslot * 16) = z;
+        *(float4v*)(smem + PATCH_BYTES + p * ROWB + lslot * 16) = z;
+      }
+    }
+    // weights: LDS row R (MFMA-tile order) <- permuted source channel so that a lane ends up with 8 consecutive
+    // output channels (see conv_igemm.hip): R = blk*64 + mt*16 + r
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) {
+      const int R = i * 64 + wave * 16 + lrow;
+      const int blk = R >> 6, Rl = R & 63;
+      const int mt = Rl >> 4, r = Rl & 15;
+      const int chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
+      const int cc = lslot ^ (((R >> 2) & 1) << 1);
+      wrow[i] = a.w + (long)(tch + blk * 64 + chl) * a.Kpad + cc * 8;
+    }
+  };
+  auto issue_patch_piece = [&](int chunk, int i) __attribute__((always_inline)) {
+    if ((pok >> i) & 1u) glds16(xb + poff[i] + chunk * 32, smem + (chunk & 1) * PATCH_BYTES + (wave + 4 * i) * 1024);
+  };
+  auto issue_weights = [&](int chunk, int tap, int buf) __attribute__((always_inline)) {
+    const int koff = tap * a.Cin + chunk * 32;
+#pragma unroll
+    for (int i = 0; i < W_IT; ++i) glds16(wrow[i] + koff, wbase + buf * WBUF + (i * 64 + wave * 16) * ROWB);
+  };
+  // tile prologue: bias (oldest DMA, so every counted wait covers it), patch of chunk 0, weights of steps 0..NWB-1
+  // (all taps of chunk 0: NWB <= 9).  Exactly (NWB - 1) * W_IT of these are younger than stage 0.
+  auto issue_prologue = [&](int par) __attribute__((always_inline)) {
+    if (wave < 2) glds4(a.bias + tch + wave * 64 + lane, sbias + par * BCH + wave * 64);
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, i);
+#pragma unroll
+    for (int i = 0; i < NWB; ++i) issue_weights(0, i, i);
+  };
+
   float4v acc[MT][NT];
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
   half8 af0[MT], af1[MT], bf[NT];
+  // epilogue of a finished tile (bias from LDS, SiLU, residual, fp16 pack, 16-byte stores at a channel offset)
+  auto epilogue = [&](int eb, int ey0, int ex0, int ech, int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int iy = ey0 + wpx * NT + nt, ix = ex0 + l15;
+      if (iy >= H || ix >= W) continue;
+      const long pix = (long)iy * W + ix;
+#pragma unroll
+      for (int sg = 0; sg < MT / 2; ++sg) {
+        const int chl = wch * 64 + sg * 32 + g * 8;
+        const int ch0 = ech + chl;
+        if (ch0 >= a.Cout) continue;
+        const float4v b0 = *(const float4v*)(sbias + par * BCH + chl), b1 = *(const float4v*)(sbias + par * BCH + chl + 4);
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[j] = acc[2 * sg][nt][j] + b0[j];
+          v[4 + j] = acc[2 * sg + 1][nt][j] + b1[j];
+        }
+        if (a.act && !(a.dbg & 4)) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
+        }
+        if (a.res) {
+          const half8 rv = *(const half8*)(a.res + (long)eb * a.r_bstride + pix * a.ldr + ch0);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
+        }
+        if ((a.dbg & 8) && v[0] != 123.f) continue;  // dbg: no stores
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+        *(half8*)((half_t*)a.y + (long)eb * a.y_bstride + pix * a.ldy + ch0) = o;
+      }
+    }
+  };
 
-  // ---- prologue: bias (oldest DMA, so every counted wait covers it), patch of chunk 0, weights of steps
-  // 0..NWB-1 (all taps of chunk 0: NWB <= 9)
-  if (wave < 2) glds4(a.bias + ch_base + wave * 64 + lane, sbias + wave * 64);
-#pragma unroll
-  for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, i);
-#pragma unroll
-  for (int i = 0; i < NWB; ++i) issue_weights(0, i, i);
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 1) * W_IT) : "memory");  // patch 0 + stage 0 landed
-  __builtin_amdgcn_s_barrier();
-  int be = baddr(0, 0);
-#pragma unroll
-  for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(wbase + aoff + mt * 1024);
-#pragma unroll
-  for (int nt = 0; nt < NT / 2; ++nt) bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));
-
-  if (a.stamps) st1 = __builtin_amdgcn_s_memtime();
   const int nsteps = nchunks * 9;   // even: nchunks = Cin / 32 with Cin a multiple of 64
-  int chunk = 0, tap = 0;           // of step s
+  int vb = blockIdx.x;
+  decode(vb);
+  setup();
+  issue_prologue(0);
+  int par = 0, ntile = 0;
+  int pb_ = 0, py0_ = 0, px0_ = 0, pch_ = 0;   // previous tile (its accumulators are still in registers)
+  bool have_prev = false;
+  for (;;) {
+    // The finished tile's epilogue runs while this tile's prologue DMA is in flight.  Its stores are the youngest
+    // vector-memory operations, so the counted wait below lets all 16 of them (full tile) stay outstanding.
+    bool prev_full = false;
+    if (a.stamps && ntile == 1) sa = __builtin_amdgcn_s_memtime();
+    if (have_prev) {
+      prev_full = (py0_ + wpx * NT + NT <= H) && (pch_ + wch * 64 + 64 <= a.Cout) && !(a.dbg & 8);
+      epilogue(pb_, py0_, px0_, pch_, par ^ 1);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+    if (a.stamps && ntile == 1) sb = __builtin_amdgcn_s_memtime();
+    if (prev_full)
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 1) * W_IT + 2 * NT) : "memory");
+    else
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 1) * W_IT) : "memory");  // patch 0 + stage 0 landed
+    __builtin_amdgcn_s_barrier();
+    int be = baddr(0, 0);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(wbase + aoff + mt * 1024);
+#pragma unroll
+    for (int nt = 0; nt < NT / 2; ++nt) bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));
 
-  // one pipeline step; AC = A fragments of this step, AN = A fragments to load for the next one
+    if (a.stamps && ntile == 0) st1 = __builtin_amdgcn_s_memtime();
+    if (a.stamps && ntile == 1) sc = __builtin_amdgcn_s_memtime();
+    int chunk = 0, tap = 0;           // of step s
+
+    // one pipeline step; AC = A fragments of this step, AN = A fragments to load for the next one
+#define M355_SB __builtin_amdgcn_sched_barrier(0);
+#define M355_MF(AC, mt, nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+#define M355_RB(nt) bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));
+#define M355_ROW(AC, nt) M355_MF(AC, 0, nt) M355_MF(AC, 1, nt) M355_MF(AC, 2, nt) M355_MF(AC, 3, nt)
+  // The instruction order inside a step is pinned with sched_barrier(0) after every (MFMA, ds_read) pair: left to
+  // itself the scheduler clusters the reads, and a cluster of n reads idles the MFMA pipe for ~n x 16 cycles.
 #define M355_WIDE_STEP(AC, AN)                                                                                  \
   {                                                                                                              \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)           \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
-    _Pragma("unroll") for (int nt = NT / 2; nt < NT; ++nt)                                                       \
-        bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 2; nt < 4; ++nt)           \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    /* P1: 16 MFMA (image rows 0-3); the four B reads of rows 4-7 ride in the first MFMA shadows */              \
+    M355_MF(AC, 0, 0) M355_SB M355_RB(4) M355_MF(AC, 1, 0) M355_SB M355_RB(5) M355_MF(AC, 2, 0) M355_SB           \
+    M355_RB(6) M355_MF(AC, 3, 0) M355_SB M355_RB(7) M355_MF(AC, 0, 1) M355_SB                                    \
+    M355_MF(AC, 1, 1) M355_MF(AC, 2, 1) M355_MF(AC, 3, 1) M355_ROW(AC, 2) M355_ROW(AC, 3) M355_SB                \
     if (s + NWB - 1 < nsteps)                                                                                    \
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 2) * W_IT) : "memory");                         \
     else                                                                                                         \
@@ -193,76 +264,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     if (t1 == 9) { t1 = 0; ++c1; }                                                                               \
     int cN = chunk, tN = tap + NWB;                                                                              \
     if (tN >= 9) { tN -= 9; ++cN; }                                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 4; nt < 6; ++nt)           \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    /* P2a: LDS-DMA of stage s+NWB (+ one patch piece of the next chunk) */                                      \
     if (s + NWB < nsteps && !(a.dbg & 2)) issue_weights(cN, tN, s & (NWB - 1));                                  \
     if (tap < P_IT && chunk + 1 < nchunks && !(a.dbg & 1)) {                                                     \
       _Pragma("unroll") for (int i = 0; i < P_IT; ++i) if (i == tap) issue_patch_piece(chunk + 1, i);            \
     }                                                                                                            \
     be = baddr(c1, t1);                                                                                          \
-    {                                                                                                            \
-      const char* wn = wbase + ((s + 1) & (NWB - 1)) * WBUF + aoff;                                              \
-      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) AN[mt] = *(const half8*)(wn + mt * 1024);                \
-    }                                                                                                            \
-    _Pragma("unroll") for (int nt = 0; nt < NT / 2; ++nt)                                                        \
-        bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));                              \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 6; nt < 8; ++nt)           \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);            \
-    __builtin_amdgcn_sched_barrier(0);                                                                           \
+    const char* wn = wbase + ((s + 1) & (NWB - 1)) * WBUF + aoff;                                                \
+    M355_SB                                                                                                      \
+    /* P2b: 16 MFMA (rows 4-7) with the eight reads of step s+1 (A, then B rows 0-3) between them */             \
+    M355_MF(AC, 0, 4) M355_SB                                                                                    \
+    AN[0] = *(const half8*)(wn); M355_MF(AC, 1, 4) M355_SB                                                       \
+    AN[1] = *(const half8*)(wn + 1024); M355_MF(AC, 2, 4) M355_SB                                                \
+    AN[2] = *(const half8*)(wn + 2048); M355_MF(AC, 3, 4) M355_SB                                                \
+    AN[3] = *(const half8*)(wn + 3072); M355_MF(AC, 0, 5) M355_SB                                                \
+    M355_RB(0) M355_MF(AC, 1, 5) M355_SB M355_RB(1) M355_MF(AC, 2, 5) M355_SB                                    \
+    M355_RB(2) M355_MF(AC, 3, 5) M355_SB M355_RB(3) M355_MF(AC, 0, 6) M355_SB                                    \
+    M355_MF(AC, 1, 6) M355_MF(AC, 2, 6) M355_MF(AC, 3, 6) M355_ROW(AC, 7) M355_SB                                \
     chunk = c1;                                                                                                  \
     tap = t1;                                                                                                    \
     ++s;                                                                                                         \
   }
 
-  for (int s = 0; s < nsteps;) {
-    M355_WIDE_STEP(af0, af1)
-    M355_WIDE_STEP(af1, af0)
-  }
-#undef M355_WIDE_STEP
-
-  if (a.stamps) st2 = __builtin_amdgcn_s_memtime();
-  // ---- epilogue (bias from LDS, SiLU, residual, fp16 pack, 16-byte stores at a channel offset)
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int iy = y0 + wpx * NT + nt, ix = x0 + l15;
-    if (iy >= H || ix >= W) continue;
-    const long pix = (long)iy * W + ix;
-#pragma unroll
-    for (int sg = 0; sg < MT / 2; ++sg) {
-      const int chl = wch * 64 + sg * 32 + g * 8;
-      const int ch0 = ch_base + chl;
-      if (ch0 >= a.Cout) continue;
-      const float4v b0 = *(const float4v*)(sbias + chl), b1 = *(const float4v*)(sbias + chl + 4);
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        v[j] = acc[2 * sg][nt][j] + b0[j];
-        v[4 + j] = acc[2 * sg + 1][nt][j] + b1[j];
-      }
-      if (a.act && !(a.dbg & 4)) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = silu_f(v[j]);
-      }
-      if (a.res) {
-        const half8 rv = *(const half8*)(a.res + (long)b * a.r_bstride + pix * a.ldr + ch0);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
-      }
-      if ((a.dbg & 8) && v[0] != 123.f) continue;  // dbg: no stores
-      half8 o;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
-      *(half8*)((half_t*)a.y + (long)b * a.y_bstride + pix * a.ldy + ch0) = o;
+    for (int s = 0; s < nsteps;) {
+      M355_WIDE_STEP(af0, af1)
+      M355_WIDE_STEP(af1, af0)
     }
+#undef M355_WIDE_STEP
+#undef M355_SB
+#undef M355_MF
+#undef M355_RB
+#undef M355_ROW
+
+    if (a.stamps && ntile == 0) st2 = __builtin_amdgcn_s_memtime();
+    if (a.stamps && ntile == 1) sd = __builtin_amdgcn_s_memtime();
+    // After the last step's barrier no wave reads live LDS data any more (its second half only pre-reads the
+    // never-used step nsteps), so the next tile's zero fill and DMA may start without another barrier.
+    pb_ = tb; py0_ = ty0; px0_ = tx0; pch_ = tch;
+    have_prev = true;
+    par ^= 1;
+    ++ntile;
+    vb += gridDim.x;
+    if (vb >= ntiles) break;
+    decode(vb);
+    setup();
+    issue_prologue(par);
   }
+  epilogue(pb_, py0_, px0_, pch_, par ^ 1);
   if (a.stamps && tid == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long st3 = __builtin_amdgcn_s_memtime();
-    unsigned long long* o = a.stamps + (long)blockIdx.x * 8;
+    unsigned long long* o = a.stamps + (long)blockIdx.x * 8;  // [0..2]: first tile; [3]: block end; [6]: tiles done
     o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+    o[6] = (unsigned long long)ntile;
+    unsigned long long* o2 = a.stamps + (1 << 19) + (long)blockIdx.x * 4;  // second tile: epilogue start / end, loop start / end
+    o2[0] = sa; o2[1] = sb; o2[2] = sc; o2[3] = sd;
   }
 }
 
@@ -280,14 +336,21 @@ int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s) {
   const int tiles_x = (a.Wi + TS - 1) / TS, tiles_y = (a.Hi + TH - 1) / TH;
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;
   const int B = a.M / (a.Ho * a.Wo);
-  static bool attr_set = false;
-  if (!attr_set) {
+  const int ntiles = B * tiles_y * tiles_x * tiles_ch;
+  static int slots = 0;   // resident blocks: two per CU
+  if (!slots) {
     hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
-    attr_set = true;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return -2;
+    const char* ev = getenv("M355_WIDE_SLOTS");
+    slots = ev ? atoi(ev) : 2 * cus;
+    if (slots < 8) slots = 8;
+    slots &= ~7;   // the XCD-aware tile order needs gridDim.x % 8 == 0 whenever a block walks more than one tile
   }
-  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(B * tiles_y * tiles_x * tiles_ch), dim3(256), LDS_BYTES, s, a, tiles_x,
-                     tiles_y, a.Cin / 32);
+  const int grid = ntiles <= slots ? ntiles : slots;
+  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a, tiles_x, tiles_y, a.Cin / 32, ntiles);
   return (int)hipGetLastError();
 }
 

@@ -428,6 +428,7 @@ void annotate_ops(m355_engine* e) {
         }
         op.tile = conv_pick_tile(cout_v, e->desc.max_batch * Ho * Wo);
         if (k == 1 && op.tile == TILE_128x128 && getenv("M355_K1_TILE")) op.tile = atoi(getenv("M355_K1_TILE"));
+        bool wide = false;
         {
           ConvArgs probe{};
           probe.ksize = p.k; probe.stride = p.stride; probe.pad = p.k / 2; probe.out_f32 = (op.out_ext == 1);
@@ -435,8 +436,11 @@ void annotate_ops(m355_engine* e) {
           probe.Cin = p.cin; probe.Cout = cout_v; probe.Hi = ti.H; probe.Wi = ti.W; probe.Ho = Ho; probe.Wo = Wo;
           probe.ldx = 8; probe.ldy = 8;
           if (op.kind == OP_CONV && conv3x3_halo_ok(probe) && !getenv("M355_NO_HALO")) op.tile = TILE_HALO;
+          wide = op.tile == TILE_HALO && conv3x3_wide_ok(probe) && !getenv("M355_NO_WIDE");
         }
-        if (op.tile == TILE_HALO)
+        if (wide)
+          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_wide<128ch,16x16px>");
+        else if (op.tile == TILE_HALO)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_halo<%s>", cout_v > 64 ? "128ch" : "64ch");
         else
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d>", tile_names[op.tile], k);

@@ -14,14 +14,27 @@ def run(B, H, W, cin, cout, k, mfma_per_wave):
     for _ in range(2):
         _capi.check(_capi.lib.m355_conv2d_fwd(P(x), B, H, W, cin, P(w), P(b), cout, k, 1, 1, P(None), P(y), 0, tile | (dbg << 8),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    s = np.fromfile("/tmp/stamps.bin", dtype=np.uint64).reshape(-1, 8)
+    raw = np.fromfile("/tmp/stamps.bin", dtype=np.uint64)
+    s2 = raw[1 << 19:].reshape(-1, 4).astype(np.int64)
+    s2 = s2[s2[:, 0] > 0]
+    if len(s2):
+        print(f"   second tile med: epilogue(prev) {np.median(s2[:, 1] - s2[:, 0]):.0f}  wait+barrier+first reads {np.median(s2[:, 2] - s2[:, 1]):.0f}"
+              f"  main loop {np.median(s2[:, 3] - s2[:, 2]):.0f} cycles")
+    s = raw[:1 << 19].reshape(-1, 8)
     s = s[s[:, 0] > 0].astype(np.int64)
     pro = s[:, 1] - s[:, 0]; main = s[:, 2] - s[:, 1]; epi = s[:, 3] - s[:, 2]; tot = s[:, 3] - s[:, 0]
     rt = (s[:, 5] - s[:, 4]).clip(1)
     clk = np.median(tot / rt) * 100e6
     span_rt = (s[:, 5].max() - s[:, 4].min()) / 100e6
     print(f"{(B, H, W, cin, cout)} tile {tile} dbg {dbg}: blocks {len(s)} kernel span {span_rt * 1e6:.1f} us, in-kernel clock {clk / 1e9:.2f} GHz")
+    if s[:, 6].max() > 0:
+        nt = s[:, 6].clip(1)
+        print(f"   persistent: tiles/block med {np.median(nt):.0f}, cycles per tile (block lifetime / tiles) med {np.median(tot / nt):.0f};"
+              f" MFMA share 2 x {mfma_per_wave * 16} / that = {2 * mfma_per_wave * 16 / np.median(tot / nt):.2f}")
     print(f"   cycles med: prologue {np.median(pro):.0f} main {np.median(main):.0f} epilogue {np.median(epi):.0f} total {np.median(tot):.0f};"
           f" MFMA cycles/wave {mfma_per_wave * 16} -> x2 waves/SIMD = {2 * mfma_per_wave * 16 / np.median(main):.2f} of the main loop")
 run(32, 160, 160, 128, 128, 3, 18 * 32)
-run(32, 40, 40, 128, 128, 3, 18 * 32)
+if tile != 19:
+    run(32, 40, 40, 128, 128, 3, 18 * 32)
+else:
+    run(32, 80, 80, 128, 128, 3, 18 * 32)
