@@ -61,12 +61,12 @@ constexpr int MT = 4, NT = 8;
 constexpr int LDS_BYTES = 2 * PATCH_BYTES + NWB * WBUF + 2 * BCH * 4;
 
 __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, int tiles_x, int tiles_y, int nchunks,
-                                                              int ntiles) {
+                                                              int ntiles, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wbase = smem + 2 * PATCH_BYTES;
   float* const sbias = (float*)(wbase + NWB * WBUF);   // two buffers of BCH floats (tile parity)
 
-  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0, sa = 0, sb = 0, sc = 0, sd = 0;
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0, sa = 0, sb = 0, sc = 0, sd = 0, sa2 = 0;
   if (a.stamps) {
     st0 = __builtin_amdgcn_s_memtime();
     rt0 = __builtin_amdgcn_s_memrealtime();
@@ -170,6 +170,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
   half8 af0[MT], af1[MT], bf[NT];
   // epilogue of a finished tile (bias from LDS, SiLU, residual, fp16 pack, 16-byte stores at a channel offset)
   auto epilogue = [&](int eb, int ey0, int ex0, int ech, int par) __attribute__((always_inline)) {
+    // fast path: this wave's 8 rows x 16 columns x 64 channels are all inside the tensor
+    if (ey0 + wpx * NT + NT <= H && ex0 + TS <= W && ech + wch * 64 + 64 <= a.Cout && !(a.dbg & 12)) {
+      const float* sb = sbias + par * BCH + wch * 64 + g * 8;
+      float4v bv[MT / 2][2];
+#pragma unroll
+      for (int sg = 0; sg < MT / 2; ++sg) {
+        bv[sg][0] = *(const float4v*)(sb + sg * 32);
+        bv[sg][1] = *(const float4v*)(sb + sg * 32 + 4);
+      }
+      const long pix0 = (long)(ey0 + wpx * NT) * W + ex0 + l15;
+      const int cho = ech + wch * 64 + g * 8;
+      half_t* yp = (half_t*)a.y + (long)eb * a.y_bstride + pix0 * a.ldy + cho;
+      const long ystep = (long)W * a.ldy;
+      if (a.res) {
+        const half_t* rp = a.res + (long)eb * a.r_bstride + pix0 * a.ldr + cho;
+        const long rstep = (long)W * a.ldr;
+        if (a.act) conv_epilogue_fast<MT, NT, true, true>(acc, bv, yp, ystep, rp, rstep);
+        else conv_epilogue_fast<MT, NT, false, true>(acc, bv, yp, ystep, rp, rstep);
+      } else {
+        if (a.act) conv_epilogue_fast<MT, NT, true, false>(acc, bv, yp, ystep, nullptr, 0);
+        else conv_epilogue_fast<MT, NT, false, false>(acc, bv, yp, ystep, nullptr, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int iy = ey0 + wpx * NT + nt, ix = ex0 + l15;
@@ -206,6 +230,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
   };
 
   const int nsteps = nchunks * 9;   // even: nchunks = Cin / 32 with Cin a multiple of 64
+  // Two blocks share a CU and would run in lockstep (same tile size), so their epilogues -- 512 quarter-rate
+  // exp / rcp per lane, no MFMA -- would coincide on the SIMDs.  The block whose LDS allocation does not start at
+  // 0 is the CU's second one: it starts late, so that one block's epilogue runs under the other's main loop.
+  if (stagger > 0 && (__builtin_amdgcn_s_getreg((6 /*HW_REG_LDS_ALLOC*/) | (0 << 6) | (11 << 11)) != 0)) {
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   int vb = blockIdx.x;
   decode(vb);
   setup();
@@ -218,6 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     // vector-memory operations, so the counted wait below lets all 16 of them (full tile) stay outstanding.
     bool prev_full = false;
     if (a.stamps && ntile == 1) sa = __builtin_amdgcn_s_memtime();
+    if (a.stamps && ntile == 2) sa2 = __builtin_amdgcn_s_memtime();
     if (have_prev) {
       prev_full = (py0_ + wpx * NT + NT <= H) && (pch_ + wch * 64 + 64 <= a.Cout) && !(a.dbg & 8);
       epilogue(pb_, py0_, px0_, pch_, par ^ 1);
@@ -245,7 +276,13 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     // one pipeline step; AC = A fragments of this step, AN = A fragments to load for the next one
 #define M355_SB __builtin_amdgcn_sched_barrier(0);
 #define M355_MF(AC, mt, nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);
+#ifdef M355_ABL_NOREADS
+#define M355_RB(nt)
+#define M355_RA(AN, i)
+#else
 #define M355_RB(nt) bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));
+#define M355_RA(AN, i) AN[i] = *(const half8*)(wn + i * 1024);
+#endif
 #define M355_ROW(AC, nt) M355_MF(AC, 0, nt) M355_MF(AC, 1, nt) M355_MF(AC, 2, nt) M355_MF(AC, 3, nt)
   // The instruction order inside a step is pinned with sched_barrier(0) after every (MFMA, ds_read) pair: left to
   // itself the scheduler clusters the reads, and a cluster of n reads idles the MFMA pipe for ~n x 16 cycles.
@@ -259,7 +296,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 2) * W_IT) : "memory");                         \
     else                                                                                                         \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                \
-    __builtin_amdgcn_s_barrier();                                                                                \
+    if (!(a.dbg & 16)) __builtin_amdgcn_s_barrier();                                                             \
     int c1 = chunk, t1 = tap + 1;                                                                                \
     if (t1 == 9) { t1 = 0; ++c1; }                                                                               \
     int cN = chunk, tN = tap + NWB;                                                                              \
@@ -274,10 +311,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     M355_SB                                                                                                      \
     /* P2b: 16 MFMA (rows 4-7) with the eight reads of step s+1 (A, then B rows 0-3) between them */             \
     M355_MF(AC, 0, 4) M355_SB                                                                                    \
-    AN[0] = *(const half8*)(wn); M355_MF(AC, 1, 4) M355_SB                                                       \
-    AN[1] = *(const half8*)(wn + 1024); M355_MF(AC, 2, 4) M355_SB                                                \
-    AN[2] = *(const half8*)(wn + 2048); M355_MF(AC, 3, 4) M355_SB                                                \
-    AN[3] = *(const half8*)(wn + 3072); M355_MF(AC, 0, 5) M355_SB                                                \
+    M355_RA(AN, 0) M355_MF(AC, 1, 4) M355_SB                                                                        \
+    M355_RA(AN, 1) M355_MF(AC, 2, 4) M355_SB                                                                         \
+    M355_RA(AN, 2) M355_MF(AC, 3, 4) M355_SB                                                                         \
+    M355_RA(AN, 3) M355_MF(AC, 0, 5) M355_SB                                                                         \
     M355_RB(0) M355_MF(AC, 1, 5) M355_SB M355_RB(1) M355_MF(AC, 2, 5) M355_SB                                    \
     M355_RB(2) M355_MF(AC, 3, 5) M355_SB M355_RB(3) M355_MF(AC, 0, 6) M355_SB                                    \
     M355_MF(AC, 1, 6) M355_MF(AC, 2, 6) M355_MF(AC, 3, 6) M355_ROW(AC, 7) M355_SB                                \
@@ -294,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
 #undef M355_SB
 #undef M355_MF
 #undef M355_RB
+#undef M355_RA
 #undef M355_ROW
 
     if (a.stamps && ntile == 0) st2 = __builtin_amdgcn_s_memtime();
@@ -319,6 +357,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     o[6] = (unsigned long long)ntile;
     unsigned long long* o2 = a.stamps + (1 << 19) + (long)blockIdx.x * 4;  // second tile: epilogue start / end, loop start / end
     o2[0] = sa; o2[1] = sb; o2[2] = sc; o2[3] = sd;
+    a.stamps[(1 << 19) + (1 << 18) + blockIdx.x] = sa2;
   }
 }
 
@@ -350,7 +389,13 @@ int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s) {
     slots &= ~7;   // the XCD-aware tile order needs gridDim.x % 8 == 0 whenever a block walks more than one tile
   }
   const int grid = ntiles <= slots ? ntiles : slots;
-  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a, tiles_x, tiles_y, a.Cin / 32, ntiles);
+  static int stagger = -1;
+  if (stagger < 0) {
+    const char* ev = getenv("M355_WIDE_STAGGER");
+    stagger = ev ? atoi(ev) : 0;
+  }
+  hipLaunchKernelGGL(conv3x3_wide_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a, tiles_x, tiles_y, a.Cin / 32, ntiles,
+                     ntiles > grid ? stagger : 0);
   return (int)hipGetLastError();
 }
 

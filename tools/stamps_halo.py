@@ -15,7 +15,11 @@ def run(B, H, W, cin, cout, k, mfma_per_wave):
         _capi.check(_capi.lib.m355_conv2d_fwd(P(x), B, H, W, cin, P(w), P(b), cout, k, 1, 1, P(None), P(y), 0, tile | (dbg << 8),
                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     raw = np.fromfile("/tmp/stamps.bin", dtype=np.uint64)
-    s2 = raw[1 << 19:].reshape(-1, 4).astype(np.int64)
+    s2 = raw[1 << 19:(1 << 19) + (1 << 18)].reshape(-1, 4).astype(np.int64)
+    s3 = raw[(1 << 19) + (1 << 18):].astype(np.int64)[:len(s2)]
+    okm = (s2[:, 0] > 0) & (s3 > 0)
+    if okm.any():
+        print(f"   main end of tile 1 -> loop top of tile 2 (decode + setup + prologue issue) med {np.median((s3 - s2[:, 3])[okm]):.0f} cycles")
     s2 = s2[s2[:, 0] > 0]
     if len(s2):
         print(f"   second tile med: epilogue(prev) {np.median(s2[:, 1] - s2[:, 0]):.0f}  wait+barrier+first reads {np.median(s2[:, 2] - s2[:, 1]):.0f}"
