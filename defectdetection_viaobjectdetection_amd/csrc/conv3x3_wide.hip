@@ -48,18 +48,25 @@ __device__ __forceinline__ float silu_f(float v) {
 constexpr int TS = 16, TH = 16;       // output tile
 constexpr int PP = 20;                // patch row pitch in pixels (18 used)
 constexpr int PH = TH + 2;
-constexpr int PROWS = PH * PP;        // 360 LDS rows per patch buffer
+constexpr int PROWS = 368;            // 18 x 20 patch pixels + 8 rows the last DMA piece spills into (never read)
 constexpr int ROWB = 64;              // LDS row = 32 halves
-constexpr int PATCH_BYTES = PROWS * ROWB;          // 23040
-constexpr int PPIECES = (PROWS + 15) / 16;         // 23 DMA pieces of 16 rows
-constexpr int P_IT = (PPIECES + 3) / 4;            // 6 per wave
+constexpr int PATCH_BYTES = PROWS * ROWB;          // 23552
 constexpr int BCH = 128;
 constexpr int WBUF = BCH * ROWB;                   // 8192
-constexpr int NWB = 4;
+constexpr int NWB = 3;                             // weight ring: the slot of a step is its kw
 constexpr int W_IT = BCH / (4 * 16);               // 2 weight pieces per wave per step
 constexpr int MT = 4, NT = 8;
 constexpr int LDS_BYTES = 2 * PATCH_BYTES + NWB * WBUF + 2 * BCH * 4;
 
+// Instruction economy is the design rule of this kernel.  A wave issues one instruction per four cycles, and 32 MFMAs
+// of 16 cycles leave 96 issue slots per step for everything else; the first version spent ~170 (a six-way EXEC-masked
+// chain selecting the patch piece, 64-bit address adds, tap / chunk wrap arithmetic) and a wave alone needed 1,230
+// cycles per 512-cycle step.  Here:
+//   * K runs in ROWS of three steps (one kh, kw = 0, 1, 2 as compile-time constants): the weight ring slot is kw,
+//     the weights of row r+1 / step kw are fetched at row r / step kw, all per-row scalars are computed once per row;
+//   * the patch of the next chunk streams in 9 affine pieces: at tap t waves 0-2 load LDS rows 40 t .. 40 t + 47
+//     (= patch rows 2t, 2t+1 and the first 8 pixels of 2t+2, rewritten identically by tap t+1), source offset
+//     = lane base + t * 2 W ldx; out-of-image pixels read a zero page instead of being EXEC-masked.
 __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, int tiles_x, int tiles_y, int nchunks,
                                                               int ntiles, int stagger) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -85,12 +92,22 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
   const int aoff = (wch * 64 + l15) * ROWB + ((g ^ (((l15 >> 2) & 1) << 1)) << 4);   // + mt * 1024 (immediate)
   const int pb = (wpx * NT) * PP + l15;                                                // patch row of (image row 0, x = l15)
   const int g16 = g << 4;
-  // byte address of the B fragment of image row 0 at (chunk, tap); odd rows use addr ^ 32; row nt adds nt * 1280
-  auto baddr = [&](int chunk, int tap) __attribute__((always_inline)) -> int {
-    const int kh = (tap * 11) >> 5, kw = tap - 3 * kh;
-    const int p = pb + kh * PP + kw;
-    return (chunk & 1) * PATCH_BYTES + (p << 6) + (g16 ^ ((p & 4) << 3));
-  };
+
+  // ---- patch streaming lane constants (waves 0-2): LDS row 40 t + r0 at tap t
+  const int r0 = wave * 16 + lrow;
+  const int pdy = r0 / PP, ppx = r0 - pdy * PP;
+  const int pcc = lslot ^ (((r0 >> 2) & 1) << 1);                 // (40 t + r0) >> 2 has the parity of r0 >> 2
+  // ---- weight streaming lane constant: LDS row R = i*64 + wave*16 + lrow holds permuted channel chl of block i
+  int wlane;   // byte offset of this lane's 16 bytes inside the weight matrix of a channel tile (piece i adds 64 rows)
+  {
+    const int Rl = wave * 16 + lrow;
+    const int mt = Rl >> 4, r = Rl & 15;
+    const int chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
+    const int cc = lslot ^ (((Rl >> 2) & 1) << 1);
+    wlane = (chl * a.Kpad + cc * 8) * 2;
+  }
+  const long wblk = (long)64 * a.Kpad * 2;                        // bytes between the two 64-channel blocks
+  const int prow_bytes = 2 * W * a.ldx * 2;                       // two image rows, in bytes
 
   // ---- persistent walk over tiles: virtual block vb = blockIdx.x + k * gridDim.x (gridDim.x is a multiple of 8 or
   // equals ntiles, so vb & 7 is this block's XCD for every k).  XCD-aware order: the virtual blocks of one XCD cover
@@ -111,59 +128,41 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
   };
 
   // ---- per-tile loader state
-  int poff[P_IT];
-  unsigned pok;
-  const half_t* xb;
-  const half_t* wrow[W_IT];
+  const char* xlane;       // this lane's patch source at tap 0, chunk 0 (may point outside the image: see pvalid)
+  int iy0;                 // image row of that source
+  unsigned hlim;           // rows iy with (unsigned)iy < hlim are loadable (inside the image and inside the patch)
+  bool col_ok;             // this lane's patch column is inside the image
+  const char* wtile;       // weight matrix of the tile's channel block (uniform)
   auto setup = [&]() __attribute__((always_inline)) {
-    xb = a.x + (long)tb * a.x_bstride;
-    pok = 0;
-    // patch: this wave owns pieces j = wave + 4*i; lane = (LDS row 16j + lane/4, slot lane%4)
-#pragma unroll
-    for (int i = 0; i < P_IT; ++i) {
-      const int j = wave + 4 * i;
-      const int p = 16 * j + lrow;                       // LDS row = patch pixel index (pitch 20)
-      const int py = p / PP, px = p - py * PP;
-      const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-      const bool in_patch = p < PROWS && px < PH;        // PH == 18 == used patch width
-      const bool ok = in_patch && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const int cc = lslot ^ (((p >> 2) & 1) << 1);      // source chunk that belongs in this slot
-      poff[i] = (iy * W + ix) * a.ldx + cc * 8;
-      if (ok) pok |= 1u << i;
-      if (p < PROWS && !ok) {                            // border / padding slot: stays zero for every chunk
-        const float4v z = {0.f, 0.f, 0.f, 0.f};
-        *(float4v*)(smem + p * ROWB + lslot * 16) = z;
-        *(float4v*)(smem + PATCH_BYTES + p * ROWB + lslot * 16) = z;
-      }
-    }
-    // weights: LDS row R (MFMA-tile order) <- permuted source channel so that a lane ends up with 8 consecutive
-    // output channels (see conv_igemm.hip): R = blk*64 + mt*16 + r
-#pragma unroll
-    for (int i = 0; i < W_IT; ++i) {
-      const int R = i * 64 + wave * 16 + lrow;
-      const int blk = R >> 6, Rl = R & 63;
-      const int mt = Rl >> 4, r = Rl & 15;
-      const int chl = (mt >> 1) * 32 + (r >> 2) * 8 + (mt & 1) * 4 + (r & 3);
-      const int cc = lslot ^ (((R >> 2) & 1) << 1);
-      wrow[i] = a.w + (long)(tch + blk * 64 + chl) * a.Kpad + cc * 8;
-    }
+    iy0 = ty0 - 1 + pdy;
+    const int ix = tx0 - 1 + ppx;
+    col_ok = ppx < PH && (unsigned)ix < (unsigned)W;
+    const int hl = ty0 - 1 + PH;
+    hlim = (unsigned)(hl < H ? hl : H);
+    xlane = (const char*)(a.x + (long)tb * a.x_bstride + ((long)iy0 * W + ix) * a.ldx + pcc * 8);
+    wtile = (const char*)(a.w + (long)tch * a.Kpad);
   };
-  auto issue_patch_piece = [&](int chunk, int i) __attribute__((always_inline)) {
-    if ((pok >> i) & 1u) glds16(xb + poff[i] + chunk * 32, smem + (chunk & 1) * PATCH_BYTES + (wave + 4 * i) * 1024);
+  // tap t of chunk c: LDS rows 40 t + [0, 48) of buffer c & 1
+  auto issue_patch_piece = [&](int c, int t) __attribute__((always_inline)) {
+    const bool ok = col_ok && (unsigned)(iy0 + 2 * t) < hlim;
+    const char* src = ok ? xlane + ((long)t * prow_bytes + c * 64) : (const char*)a.zero;
+    glds16(src, smem + (c & 1) * PATCH_BYTES + t * (40 * ROWB) + wave * 1024);
   };
-  auto issue_weights = [&](int chunk, int tap, int buf) __attribute__((always_inline)) {
-    const int koff = tap * a.Cin + chunk * 32;
+  // weights of (chunk c, tap t) into ring slot `slot`; koff2 = byte offset of that K slice inside a weight row
+  auto issue_weights = [&](int koff2, int slot) __attribute__((always_inline)) {
+    const char* w0 = wtile + koff2;
 #pragma unroll
-    for (int i = 0; i < W_IT; ++i) glds16(wrow[i] + koff, wbase + buf * WBUF + (i * 64 + wave * 16) * ROWB);
+    for (int i = 0; i < W_IT; ++i) glds16(w0 + i * wblk + (unsigned)wlane, wbase + slot * WBUF + (i * 64 + wave * 16) * ROWB);
   };
-  // tile prologue: bias (oldest DMA, so every counted wait covers it), patch of chunk 0, weights of steps 0..NWB-1
-  // (all taps of chunk 0: NWB <= 9).  Exactly (NWB - 1) * W_IT of these are younger than stage 0.
+  // tile prologue: bias (oldest DMA, so every counted wait covers it), patch of chunk 0, weights of row 0.
+  // Exactly (NWB - 1) * W_IT of these are younger than stage 0.
   auto issue_prologue = [&](int par) __attribute__((always_inline)) {
     if (wave < 2) glds4(a.bias + tch + wave * 64 + lane, sbias + par * BCH + wave * 64);
+    if (wave < 3) {
+      for (int t = 0; t < 9; ++t) issue_patch_piece(0, t);
+    }
 #pragma unroll
-    for (int i = 0; i < P_IT; ++i) issue_patch_piece(0, i);
-#pragma unroll
-    for (int i = 0; i < NWB; ++i) issue_weights(0, i, i);
+    for (int kw = 0; kw < NWB; ++kw) issue_weights(kw * a.Cin * 2, kw);
   };
 
   float4v acc[MT][NT];
@@ -229,10 +228,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     }
   };
 
-  const int nsteps = nchunks * 9;   // even: nchunks = Cin / 32 with Cin a multiple of 64
-  // Two blocks share a CU and would run in lockstep (same tile size), so their epilogues -- 512 quarter-rate
-  // exp / rcp per lane, no MFMA -- would coincide on the SIMDs.  The block whose LDS allocation does not start at
-  // 0 is the CU's second one: it starts late, so that one block's epilogue runs under the other's main loop.
+  const int nrows = nchunks * 3;   // K rows (chunk, kh); even because Cin is a multiple of 64
+  // Two blocks share a CU and would run in lockstep (same tile size): their epilogues (512 quarter-rate exp / rcp per
+  // lane, no MFMA) would coincide and their main loops would fight for the MFMA pipe.  The block whose LDS allocation
+  // does not start at 0 is the CU's second one: it starts late, so one block's epilogue runs under the other's loop.
   if (stagger > 0 && (__builtin_amdgcn_s_getreg((6 /*HW_REG_LDS_ALLOC*/) | (0 << 6) | (11 << 11)) != 0)) {
     for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
   }
@@ -263,7 +262,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     else
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 1) * W_IT) : "memory");  // patch 0 + stage 0 landed
     __builtin_amdgcn_s_barrier();
-    int be = baddr(0, 0);
+
+    // ---- row state: (chunk, kh) of the current row, its patch buffer and B base; the same for the next row
+    int chunk = 0, kh = 0;
+    int pbuf = 0, pbk = pb;
+    int be = pbuf + (pbk << 6) + (g16 ^ ((pbk & 4) << 3));
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) af0[mt] = *(const half8*)(wbase + aoff + mt * 1024);
 #pragma unroll
@@ -271,63 +274,71 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
 
     if (a.stamps && ntile == 0) st1 = __builtin_amdgcn_s_memtime();
     if (a.stamps && ntile == 1) sc = __builtin_amdgcn_s_memtime();
-    int chunk = 0, tap = 0;           // of step s
 
-    // one pipeline step; AC = A fragments of this step, AN = A fragments to load for the next one
 #define M355_SB __builtin_amdgcn_sched_barrier(0);
 #define M355_MF(AC, mt, nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AC[mt], bf[nt], acc[mt][nt], 0, 0, 0);
-#ifdef M355_ABL_NOREADS
-#define M355_RB(nt)
-#define M355_RA(AN, i)
-#else
 #define M355_RB(nt) bf[nt] = *(const half8*)(smem + (be ^ ((nt & 1) << 5)) + nt * (PP * ROWB));
 #define M355_RA(AN, i) AN[i] = *(const half8*)(wn + i * 1024);
-#endif
 #define M355_ROW(AC, nt) M355_MF(AC, 0, nt) M355_MF(AC, 1, nt) M355_MF(AC, 2, nt) M355_MF(AC, 3, nt)
-  // The instruction order inside a step is pinned with sched_barrier(0) after every (MFMA, ds_read) pair: left to
-  // itself the scheduler clusters the reads, and a cluster of n reads idles the MFMA pipe for ~n x 16 cycles.
-#define M355_WIDE_STEP(AC, AN)                                                                                  \
+    // One K step with compile-time kw.  The instruction order is pinned with sched_barrier(0) after every
+    // (ds_read, MFMA) pair: left to itself the scheduler clusters the reads and idles the MFMA pipe.
+    //   P1 : 16 MFMA (image rows 0-3), the four B reads of rows 4-7 in the first shadows
+    //   mid: stage s+1 landed (counted vmcnt: only the weights issued in the previous step may be in flight), barrier
+    //   P2a: patch piece of tap 3 kh + kw for the next chunk, weights of (next row, kw) into slot kw
+    //   P2b: 16 MFMA (rows 4-7) with the eight reads of step s+1 (A, then B rows 0-3) between them
+#define M355_WIDE_STEP(AC, AN, KW)                                                                               \
   {                                                                                                              \
-    /* P1: 16 MFMA (image rows 0-3); the four B reads of rows 4-7 ride in the first MFMA shadows */              \
     M355_MF(AC, 0, 0) M355_SB M355_RB(4) M355_MF(AC, 1, 0) M355_SB M355_RB(5) M355_MF(AC, 2, 0) M355_SB           \
     M355_RB(6) M355_MF(AC, 3, 0) M355_SB M355_RB(7) M355_MF(AC, 0, 1) M355_SB                                    \
     M355_MF(AC, 1, 1) M355_MF(AC, 2, 1) M355_MF(AC, 3, 1) M355_ROW(AC, 2) M355_ROW(AC, 3) M355_SB                \
-    if (s + NWB - 1 < nsteps)                                                                                    \
-      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((NWB - 2) * W_IT) : "memory");                         \
-    else                                                                                                         \
+    if (lastrow)                                                                                                 \
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                \
-    if (!(a.dbg & 16)) __builtin_amdgcn_s_barrier();                                                             \
-    int c1 = chunk, t1 = tap + 1;                                                                                \
-    if (t1 == 9) { t1 = 0; ++c1; }                                                                               \
-    int cN = chunk, tN = tap + NWB;                                                                              \
-    if (tN >= 9) { tN -= 9; ++cN; }                                                                              \
-    /* P2a: LDS-DMA of stage s+NWB (+ one patch piece of the next chunk) */                                      \
-    if (s + NWB < nsteps && !(a.dbg & 2)) issue_weights(cN, tN, s & (NWB - 1));                                  \
-    if (tap < P_IT && chunk + 1 < nchunks && !(a.dbg & 1)) {                                                     \
-      _Pragma("unroll") for (int i = 0; i < P_IT; ++i) if (i == tap) issue_patch_piece(chunk + 1, i);            \
+    else                                                                                                         \
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(W_IT) : "memory");                                     \
+    __builtin_amdgcn_s_barrier();                                                                                \
+    if (do_p && wave < 3) issue_patch_piece(chunk + 1, 3 * kh + KW);                                             \
+    if (!lastrow) issue_weights(wnext + KW * cin2, KW);                                                          \
+    {                                                                                                            \
+      const int p = (KW < 2 ? pbk : pbk_n) + (KW + 1) % 3;                                                       \
+      be = (KW < 2 ? pbuf : pbuf_n) + (p << 6) + (g16 ^ ((p & 4) << 3));                                         \
     }                                                                                                            \
-    be = baddr(c1, t1);                                                                                          \
-    const char* wn = wbase + ((s + 1) & (NWB - 1)) * WBUF + aoff;                                                \
+    const char* wn = wbase + ((KW + 1) % 3) * WBUF + aoff;                                                       \
     M355_SB                                                                                                      \
-    /* P2b: 16 MFMA (rows 4-7) with the eight reads of step s+1 (A, then B rows 0-3) between them */             \
     M355_MF(AC, 0, 4) M355_SB                                                                                    \
-    M355_RA(AN, 0) M355_MF(AC, 1, 4) M355_SB                                                                        \
-    M355_RA(AN, 1) M355_MF(AC, 2, 4) M355_SB                                                                         \
-    M355_RA(AN, 2) M355_MF(AC, 3, 4) M355_SB                                                                         \
-    M355_RA(AN, 3) M355_MF(AC, 0, 5) M355_SB                                                                         \
+    M355_RA(AN, 0) M355_MF(AC, 1, 4) M355_SB M355_RA(AN, 1) M355_MF(AC, 2, 4) M355_SB                            \
+    M355_RA(AN, 2) M355_MF(AC, 3, 4) M355_SB M355_RA(AN, 3) M355_MF(AC, 0, 5) M355_SB                            \
     M355_RB(0) M355_MF(AC, 1, 5) M355_SB M355_RB(1) M355_MF(AC, 2, 5) M355_SB                                    \
     M355_RB(2) M355_MF(AC, 3, 5) M355_SB M355_RB(3) M355_MF(AC, 0, 6) M355_SB                                    \
     M355_MF(AC, 1, 6) M355_MF(AC, 2, 6) M355_MF(AC, 3, 6) M355_ROW(AC, 7) M355_SB                                \
-    chunk = c1;                                                                                                  \
-    tap = t1;                                                                                                    \
-    ++s;                                                                                                         \
   }
+    // per-row scalars: the next row (chunk_n, kh_n), its B base, the weight offset of the next row, prefetch flags
+#define M355_ROW_BEGIN                                                                                           \
+    int kh_n = kh + 1, chunk_n = chunk;                                                                          \
+    if (kh_n == 3) { kh_n = 0; ++chunk_n; }                                                                      \
+    const int pbuf_n = (chunk_n & 1) * PATCH_BYTES;                                                              \
+    const int pbk_n = pb + kh_n * PP;                                                                            \
+    const int wnext = (3 * kh_n * a.Cin + chunk_n * 32) * 2;                                                     \
+    const bool lastrow = row + 1 >= nrows;                                                                       \
+    const bool do_p = chunk + 1 < nchunks && !(a.dbg & 1);
+#define M355_ROW_END                                                                                             \
+    kh = kh_n; chunk = chunk_n; pbuf = pbuf_n; pbk = pbk_n; ++row;
 
-    for (int s = 0; s < nsteps;) {
-      M355_WIDE_STEP(af0, af1)
-      M355_WIDE_STEP(af1, af0)
+    const int cin2 = a.Cin * 2;
+    for (int row = 0; row < nrows;) {
+      {
+        M355_ROW_BEGIN
+        M355_WIDE_STEP(af0, af1, 0) M355_WIDE_STEP(af1, af0, 1) M355_WIDE_STEP(af0, af1, 2)
+        M355_ROW_END
+      }
+      {
+        M355_ROW_BEGIN
+        M355_WIDE_STEP(af1, af0, 0) M355_WIDE_STEP(af0, af1, 1) M355_WIDE_STEP(af1, af0, 2)
+        M355_ROW_END
+      }
     }
 #undef M355_WIDE_STEP
+#undef M355_ROW_BEGIN
+#undef M355_ROW_END
 #undef M355_SB
 #undef M355_MF
 #undef M355_RB
@@ -337,7 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
     if (a.stamps && ntile == 0) st2 = __builtin_amdgcn_s_memtime();
     if (a.stamps && ntile == 1) sd = __builtin_amdgcn_s_memtime();
     // After the last step's barrier no wave reads live LDS data any more (its second half only pre-reads the
-    // never-used step nsteps), so the next tile's zero fill and DMA may start without another barrier.
+    // never-used step after the end), so the next tile's DMA may start without another barrier.
     pb_ = tb; py0_ = ty0; px0_ = tx0; pch_ = tch;
     have_prev = true;
     par ^= 1;
