@@ -107,9 +107,20 @@ int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int l
 // packed: ~40 instructions per store, no branch.
 // ---------------------------------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// No FMA contraction in the epilogue arithmetic: the generic and the fast epilogue must give the same bits, so that an
+// image's result does not depend on whether its tile was a full one (batch size / position invariance is tested).
 __device__ __forceinline__ float m355_silu(float v) {
+#pragma clang fp contract(off)
   const float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
   return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+// Round-to-fp16 of an epilogue value.  The value is made opaque first: otherwise the compiler may fuse the last
+// multiply (or the residual add) with the conversion into v_fma_mix*_f16 for SOME elements of SOME template
+// instantiations -- one rounding instead of two, a rare 1-ulp difference that breaks bit-exact tile / batch invariance.
+__device__ __forceinline__ half_t m355_to_half(float v) {
+  asm volatile("" : "+v"(v));
+  return (half_t)v;
 }
 
 // acc[2s][nt] / acc[2s+1][nt] hold channels 8g..8g+3 / 8g+4..8g+7 of group s for pixel nt (see conv_igemm.hip);
@@ -117,6 +128,7 @@ __device__ __forceinline__ float m355_silu(float v) {
 template <int MT, int NT, bool ACT, bool RES>
 __device__ __forceinline__ void conv_epilogue_fast(float4v (&acc)[MT][NT], const float4v (&bias)[MT / 2][2], half_t* yp,
                                                    long ystep, const half_t* rp, long rstep) {
+#pragma clang fp contract(off)
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
@@ -138,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue_fast(float4v (&acc)[MT][NT], const
       }
       half8 o;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+      for (int j = 0; j < 8; ++j) o[j] = m355_to_half(v[j]);
       *(half8*)(yp + nt * ystep + s * 32) = o;
     }
   }

@@ -31,10 +31,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float v) {
-  float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
-  return v * __builtin_amdgcn_rcpf(1.0f + e);
-}
+__device__ __forceinline__ float silu_f(float v) { return m355_silu(v); }
 
 constexpr int TS = 16;            // output tile is TH rows x TS (16) pixels
 constexpr int PW = TS + 2;        // patch width (18)
@@ -169,6 +166,18 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) bf0[nt] = *(const half8*)(smem + bcur[nt]);
 
+  // Fast epilogue (common.h) when this wave's rows x 16 columns x 64 channels are all inside the tensor: the bias is
+  // fetched here, before the K loop, and waits in registers.
+  const bool fast = y0 + wpx * NT + NT <= H && x0 + TS <= W && ch_base + wch * MT * 16 + MT * 16 <= a.Cout && !(a.dbg & (12 | 256));
+  float4v bv[MT / 2][2];
+  if (fast) {
+    const float* bp = a.bias + ch_base + wch * MT * 16 + g * 8;
+#pragma unroll
+    for (int sg = 0; sg < MT / 2; ++sg) {
+      bv[sg][0] = *(const float4v*)(bp + sg * 32);
+      bv[sg][1] = *(const float4v*)(bp + sg * 32 + 4);
+    }
+  }
   if (a.stamps) st1 = __builtin_amdgcn_s_memtime();
   const int nsteps = nchunks * 9;
   int chunk = 0, tap = 0;  // of step s
@@ -240,6 +249,28 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
 
   if (a.stamps) st2 = __builtin_amdgcn_s_memtime();
   // ---- epilogue (bias, SiLU, residual, fp16 pack, 16-byte stores at a channel offset)
+  if (fast) {
+    const long pix0 = (long)(y0 + wpx * NT) * W + x0 + l15;
+    const int cho = ch_base + wch * MT * 16 + g * 8;
+    half_t* yp = (half_t*)a.y + (long)b * a.y_bstride + pix0 * a.ldy + cho;
+    const long ystep = (long)W * a.ldy;
+    if (a.res) {
+      const half_t* rp = a.res + (long)b * a.r_bstride + pix0 * a.ldr + cho;
+      const long rstep = (long)W * a.ldr;
+      if (a.act) conv_epilogue_fast<MT, NT, true, true>(acc, bv, yp, ystep, rp, rstep);
+      else conv_epilogue_fast<MT, NT, false, true>(acc, bv, yp, ystep, rp, rstep);
+    } else {
+      if (a.act) conv_epilogue_fast<MT, NT, true, false>(acc, bv, yp, ystep, nullptr, 0);
+      else conv_epilogue_fast<MT, NT, false, false>(acc, bv, yp, ystep, nullptr, 0);
+    }
+    if (a.stamps && tid == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned long long st3 = __builtin_amdgcn_s_memtime();
+      unsigned long long* o = a.stamps + (long)blockIdx.x * 8;
+      o[0] = st0; o[1] = st1; o[2] = st2; o[3] = st3; o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
+    }
+    return;
+  }
   constexpr int GROUPS = (MT >= 2) ? MT / 2 : 1;
   constexpr int GW = (MT >= 2) ? 8 : 4;
 #pragma unroll
@@ -284,12 +315,12 @@ __global__ __launch_bounds__(WCH * WPX * 64, 2) void conv3x3_halo_kernel(const C
       if (GW == 8) {
         half8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+        for (int j = 0; j < 8; ++j) o[j] = m355_to_half(v[j]);
         *(half8*)yp = o;
       } else {
         half4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+        for (int j = 0; j < 4; ++j) o[j] = m355_to_half(v[j]);
         *(half4*)yp = o;
       }
     }
@@ -336,7 +367,9 @@ bool conv3x3_halo_ok(const ConvArgs& a) {
 }
 
 // variant: 0 = auto, 1 = 8 waves / 16x16 px, 2 = 4 waves / 8x16 px
-int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s) {
+int launch_conv3x3_halo(const ConvArgs& a0, int variant, hipStream_t s) {
+  ConvArgs a = a0;
+  if (getenv("M355_NO_FAST_EPI")) a.dbg |= 256;
   if (!conv3x3_halo_ok(a)) return -1;
   if (variant == 3 || (variant == 0 && conv3x3_wide_ok(a) && !getenv("M355_NO_WIDE"))) return launch_conv3x3_wide(a, s);
   if (variant == 0) {

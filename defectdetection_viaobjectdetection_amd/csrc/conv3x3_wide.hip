@@ -36,10 +36,7 @@ __device__ __forceinline__ void glds4(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 4, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float v) {
-  float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
-  return v * __builtin_amdgcn_rcpf(1.0f + e);
-}
+__device__ __forceinline__ float silu_f(float v) { return m355_silu(v); }
 
 // s_waitcnt immediate (gfx9 encoding): vmcnt(n) lgkmcnt(0), expcnt untouched.  The builtin (unlike inline asm) is
 // visible to the compiler's own wait-count insertion, which then does not re-wait for LDS reads issued before it.
@@ -170,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
   // epilogue of a finished tile (bias from LDS, SiLU, residual, fp16 pack, 16-byte stores at a channel offset)
   auto epilogue = [&](int eb, int ey0, int ex0, int ech, int par) __attribute__((always_inline)) {
     // fast path: this wave's 8 rows x 16 columns x 64 channels are all inside the tensor
-    if (ey0 + wpx * NT + NT <= H && ex0 + TS <= W && ech + wch * 64 + 64 <= a.Cout && !(a.dbg & 12)) {
+    if (ey0 + wpx * NT + NT <= H && ex0 + TS <= W && ech + wch * 64 + 64 <= a.Cout && !(a.dbg & (12 | 256))) {
       const float* sb = sbias + par * BCH + wch * 64 + g * 8;
       float4v bv[MT / 2][2];
 #pragma unroll
@@ -222,7 +219,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wide_kernel(const ConvArgs a, 
         if ((a.dbg & 8) && v[0] != 123.f) continue;  // dbg: no stores
         half8 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+        for (int j = 0; j < 8; ++j) o[j] = m355_to_half(v[j]);
         *(half8*)((half_t*)a.y + (long)eb * a.y_bstride + pix * a.ldy + ch0) = o;
       }
     }

@@ -39,11 +39,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_dst) {
                                    (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-__device__ __forceinline__ float silu_f(float v) {
-  // v * sigmoid(v);  exp2-based, rcp approx (1 ulp) -- far inside fp16 output rounding
-  float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
-  return v * __builtin_amdgcn_rcpf(1.0f + e);
-}
+// v * sigmoid(v);  exp2-based, rcp approx (1 ulp) -- far inside fp16 output rounding (shared with the fast epilogue)
+__device__ __forceinline__ float silu_f(float v) { return m355_silu(v); }
 
 // q = n / d, r = n % d for 0 <= n < 2^24 via a float reciprocal estimate + exact integer correction.
 __device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, int& r) {
@@ -282,12 +279,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
-    for (int t = 0; t < nk; ++t) kstep();
-
-    // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
     int tile_px, tile_ch;
     fast_divmod(tile, tiles_ch, inv_tch, tile_px, tile_ch);
     const int px_base = tile_px * BPX, ch_base = tile_ch * BCH;
+    // Fast epilogue (common.h): the whole tile is inside the tensor and images are contiguous, so the output address
+    // is affine in the pixel index; the bias is fetched before the K loop and waits in registers.
+    const bool fast = MT >= 2 && !a.out_f32 && a.convt_co == 0 && px_base + BPX <= a.M && ch_base + BCH <= a.Cout &&
+                      a.y_bstride == (long)HoWo * a.ldy && (!a.res || a.r_bstride == (long)HoWo * a.ldr) && !(a.dbg & (32 | 256));
+    float4v bv[MT >= 2 ? MT / 2 : 1][2];
+    if (fast) {
+      const float* bp = a.bias + ch_base + wch * MT * 16 + g * 8;
+#pragma unroll
+      for (int sg = 0; sg < MT / 2; ++sg) {
+        bv[sg][0] = *(const float4v*)(bp + sg * 32);
+        bv[sg][1] = *(const float4v*)(bp + sg * 32 + 4);
+      }
+    }
+    for (int t = 0; t < nk; ++t) kstep();
+
+    // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
+    if (MT >= 2 && fast) {
+      const long m0 = px_base + wpx * NT * 16 + l15;
+      const int cho = ch_base + wch * MT * 16 + g * 8;
+      half_t* yp = (half_t*)a.y + m0 * a.ldy + cho;
+      const long ystep = 16L * a.ldy;
+      if (a.res) {
+        const half_t* rp = a.res + m0 * a.ldr + cho;
+        const long rstep = 16L * a.ldr;
+        if (a.act) conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, true, true>(acc, bv, yp, ystep, rp, rstep);
+        else conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, false, true>(acc, bv, yp, ystep, rp, rstep);
+      } else {
+        if (a.act) conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, true, false>(acc, bv, yp, ystep, nullptr, 0);
+        else conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, false, false>(acc, bv, yp, ystep, nullptr, 0);
+      }
+      continue;
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
       const int m = px_base + wpx * NT * 16 + nt * 16 + l15;
@@ -346,12 +372,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
           if (GW == 8) {
             half8 o;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+            for (int j = 0; j < 8; ++j) o[j] = m355_to_half(v[j]);
             *(half8*)yp = o;
           } else {
             half4 o;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = (half_t)v[j];
+            for (int j = 0; j < 4; ++j) o[j] = m355_to_half(v[j]);
             *(half4*)yp = o;
           }
         }
@@ -415,7 +441,9 @@ int conv_pick_tile(int cout, long M) {
   return TILE_32x256;
 }
 
-int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s) {
+int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
+  ConvArgs a = a0;
+  if (getenv("M355_NO_FAST_EPI")) a.dbg |= 256;
   if (a.ksize < 1 || a.ksize > 3) return -1;
   if (a.ksize == 2 && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // only the ConvT-dgrad form
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
