@@ -63,6 +63,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(W_IT >= 1 && A_IT >= 1, "tile too small");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, rt0 = 0;
+  if (a.stamps) {
+    st0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -295,7 +300,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         bv[sg][1] = *(const float4v*)(bp + sg * 32 + 4);
       }
     }
+    if (a.stamps && tile == lb) st1 = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < nk; ++t) kstep();
+    if (a.stamps && tile == lb) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
     if (MT >= 2 && fast) {
@@ -311,6 +318,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       } else {
         if (a.act) conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, true, false>(acc, bv, yp, ystep, nullptr, 0);
         else conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, false, false>(acc, bv, yp, ystep, nullptr, 0);
+      }
+      if (a.stamps && tid == 0 && tile == lb) {   // diagnostic builds only (tools/stamps_igemm.py)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* o = a.stamps + (long)blockIdx.x * 8;
+        o[0] = st0; o[1] = st1; o[2] = st2; o[3] = __builtin_amdgcn_s_memtime(); o[4] = rt0; o[5] = __builtin_amdgcn_s_memrealtime();
       }
       continue;
     }
