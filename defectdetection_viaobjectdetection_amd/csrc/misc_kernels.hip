@@ -2,6 +2,8 @@
 // upsample into a concat slice, and the Detect decode (DFL softmax-expectation + dist2bbox + sigmoid).
 // Replaces upstream aten ops reached from SegmentationModel.forward (SURVEY.md A3/A7/A8/A9;
 // call site BscanBased/yolo8_seg_predict.py:8).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace m355 {
@@ -69,6 +71,84 @@ __global__ __launch_bounds__(256) void stem_kernel(const StemArgs a) {
     for (int j = 0; j < 8; ++j) {
       const bool ok = pv && tok[j] && (unsigned)(hi0 + tkh[j]) < (unsigned)a.H && (unsigned)(wi0 + tkw[j]) < (unsigned)a.W;
       const unsigned v = ok ? (unsigned)base[toff[j]] : 0u;
+      xf[j] = (half_t)(float)v;
+    }
+    float4v acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      acc[mt] = float4v{0.f, 0.f, 0.f, 0.f};
+      acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[mt], xf, acc[mt], 0, 0, 0);
+    }
+    if (pv) {
+      half_t* yp = a.y + (long)b * a.y_bstride + ((long)ho * Wo + wo) * a.ldy;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        half4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (half_t)silu_f(acc[mt][j] * inv255 + bias[mt][j]);
+        *(half4*)(yp + mt * 16 + g * 4) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Stem, row-staged form (used when a row of W*3 bytes is a multiple of 16): one workgroup per output row.
+// The byte gathers of stem_kernel go through the texture path one byte per lane (8 VMEM instructions per
+// 16-pixel segment: the kernel ran at 1.7 TB/s).  Here the three input rows of an output row (3 x W x 3 bytes,
+// 5.8 KB at W = 640) are staged in LDS with 16-byte coalesced loads -- 16 zero bytes on either side stand for the
+// left / right padding, a row outside the image is all zeros -- and the lanes gather their taps with ds_read_u8.
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void stem_rows_kernel(const StemArgs a) {
+  constexpr int MT = COUT / 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char srow[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, g = lane >> 4;
+  const int Ho = a.H >> 1, Wo = a.W >> 1;
+  const int rowb = a.W * 3;          // bytes per input row (multiple of 16)
+  const int pitch = rowb + 32;       // LDS row: 16 zero bytes, the row, 16 zero bytes
+  const int b = blockIdx.x / Ho, ho = blockIdx.x - b * Ho;
+  const int hi0 = 2 * ho - 1;
+  {
+    const int cpr = pitch / 16;      // 16-byte chunks per LDS row
+    for (int c = threadIdx.x; c < 3 * cpr; c += 256) {
+      const int r = c / cpr, cc = c - r * cpr;
+      const int hi = hi0 + r;
+      float4v v = {0.f, 0.f, 0.f, 0.f};
+      if (cc > 0 && cc < cpr - 1 && (unsigned)hi < (unsigned)a.H)
+        v = *(const float4v*)(a.x + ((long)b * a.H + hi) * rowb + (cc - 1) * 16);
+      *(float4v*)(srow + r * pitch + cc * 16) = v;
+    }
+  }
+  half8 wf[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) wf[mt] = *(const half8*)(a.w16 + (mt * 16 + l15) * 32 + g * 8);
+  float bias[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bias[mt][j] = a.bias[mt * 16 + g * 4 + j];
+  // this lane's 8 taps: k = 8g + j -> (kh, q = kw*3 + ci): LDS byte offset relative to the window start
+  int toff[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = g * 8 + j;
+    const int kh = k / 9, q = k - kh * 9;
+    toff[j] = k < 27 ? kh * pitch + q : -1;
+  }
+  __syncthreads();
+  const float inv255 = 1.0f / 255.0f;
+  const int segs = (Wo + 15) >> 4;
+  for (int seg = wave; seg < segs; seg += 4) {
+    const int wo = seg * 16 + l15;
+    const bool pv = wo < Wo;
+    const int woc = pv ? wo : Wo - 1;
+    const unsigned char* base = srow + 16 + (2 * woc - 1) * 3;   // window start (column 2wo-1; -3 bytes = left padding)
+    half8 xf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned v = toff[j] >= 0 ? (unsigned)base[toff[j]] : 0u;
       xf[j] = (half_t)(float)v;
     }
     float4v acc[MT];
@@ -237,7 +317,24 @@ __global__ __launch_bounds__(256) void head_decode_kernel(const float* raw, long
 
 }  // namespace
 
+template <int COUT>
+static int launch_stem_rows(const StemArgs& a, hipStream_t s) {
+  const int lds = 3 * (a.W * 3 + 32);
+  hipLaunchKernelGGL(stem_rows_kernel<COUT>, dim3((unsigned)(a.B * (a.H / 2))), dim3(256), lds, s, a);
+  return (int)hipGetLastError();
+}
+
 int launch_stem(const StemArgs& a, hipStream_t s) {
+  if ((a.W * 3) % 16 == 0 && a.W % 2 == 0 && a.H % 2 == 0 && 3 * (a.W * 3 + 32) <= 64 * 1024 && !getenv("M355_STEM_GATHER")) {
+    switch (a.Cout) {
+      case 16: return launch_stem_rows<16>(a, s);
+      case 32: return launch_stem_rows<32>(a, s);
+      case 48: return launch_stem_rows<48>(a, s);
+      case 64: return launch_stem_rows<64>(a, s);
+      case 80: return launch_stem_rows<80>(a, s);
+      default: return -1;
+    }
+  }
   const long total = (long)a.B * (a.H / 2) * ((a.W / 2 + 15) / 16);  // one wave per 16-pixel segment
   long blocks = (total + 3) / 4;
   if (blocks > 256 * 32) blocks = 256 * 32;

@@ -137,10 +137,11 @@ def test_convt2x2(cuda_device):
     assert rel_l2(y, y_ref) <= 1e-3
 
 
+@pytest.mark.parametrize("hw", [(64, 96), (40, 100), (66, 80)])   # W*3 a multiple of 16 (row-staged kernel) or not (gather kernel)
 @pytest.mark.parametrize("cout", [16, 32, 48])
-def test_stem(cout, cuda_device):
+def test_stem(cout, hw, cuda_device):
     capi = _lib()
-    B, H, W = 2, 64, 96
+    B, (H, W) = 2, hw
     g = torch.Generator().manual_seed(cout)
     img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
     w = torch.randn(cout, 3, 3, 3, generator=g) / 27 ** 0.5
