@@ -63,6 +63,8 @@ struct Op {
 struct PhysConv {
   std::vector<int> logical;  // indices into convs_
   int cin = 0, cout = 0, k = 1, stride = 1, act = 1, transposed = 0;
+  int diag = 0;              // 1: block-diagonal fusion of 1x1 convs with different inputs (cin = sum of theirs)
+  double macs_px = 0;        // algorithmic MACs per output pixel (diag: sum over the blocks, not cin * cout)
   int Kpad = 0, cout_pad = 0;
   half_t* w = nullptr;
   float* bias = nullptr;
@@ -79,6 +81,7 @@ struct m355_engine {
   std::vector<bool> conv_loaded;
   std::vector<int> conv_phys;          // logical -> physical
   std::vector<int> conv_phys_off;      // output-channel offset inside the physical conv
+  std::vector<int> conv_phys_koff;     // input-channel (K) offset inside the physical conv (block-diagonal fusion)
   std::vector<PhysConv> phys;
   std::vector<Op> ops;
   int nc = 1, nm = 32, A = 0, n3 = 0, n4 = 0, n5 = 0;
@@ -137,6 +140,7 @@ struct Builder {
     e->conv_loaded.push_back(false);
     e->conv_phys.push_back(-1);
     e->conv_phys_off.push_back(0);
+    e->conv_phys_koff.push_back(0);
     return (int)e->convs.size() - 1;
   }
   int phys_from(const std::vector<int>& logicals) {
@@ -151,6 +155,28 @@ struct Builder {
       off += e->convs[li].cout;
     }
     p.cout = off;
+    p.macs_px = (double)p.cin * p.cout * p.k * p.k;
+    e->phys.push_back(p);
+    return (int)e->phys.size() - 1;
+  }
+  // 1x1 convs with DIFFERENT inputs that sit side by side in one tensor, fused into one launch with a
+  // block-diagonal weight matrix: rows = all outputs, K = all inputs, zeros off the diagonal blocks.
+  int phys_diag(const std::vector<int>& logicals) {
+    PhysConv p;
+    p.logical = logicals;
+    const m355_conv_info& c0 = e->convs[logicals[0]];
+    p.k = 1; p.stride = 1; p.act = c0.act; p.transposed = 0; p.diag = 1;
+    int off = 0, koff = 0;
+    for (int li : logicals) {
+      e->conv_phys[li] = (int)e->phys.size();
+      e->conv_phys_off[li] = off;
+      e->conv_phys_koff[li] = koff;
+      off += e->convs[li].cout;
+      koff += e->convs[li].cin;
+      p.macs_px += (double)e->convs[li].cin * e->convs[li].cout;
+    }
+    p.cout = off;
+    p.cin = koff;
     e->phys.push_back(p);
     return (int)e->phys.size() - 1;
   }
@@ -160,7 +186,7 @@ struct Builder {
       e->macs += (double)(2 * ti.H) * (2 * ti.W) * p.cin * p.cout;
     } else {
       const int Ho = (ti.H + 2 * (p.k / 2) - p.k) / p.stride + 1, Wo = (ti.W + 2 * (p.k / 2) - p.k) / p.stride + 1;
-      e->macs += (double)Ho * Wo * p.cout * p.cin * p.k * p.k;
+      e->macs += (double)Ho * Wo * p.macs_px;
     }
   }
   // Conv(+BN+SiLU) from slice `in` to slice `out`
@@ -333,15 +359,23 @@ int build_graph(m355_engine* e) {
     const int hcat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
     const Slice f{feats[l], 0, fch[l]};
     add_conv_op({l_cv2[l][0], l_cv3[l][0], l_cv4[l][0]}, f, Slice{hcat, 0, hc2 + hc3 + hc4}, 0, 0, 0);
-    const int u2 = b.tensor(HW[l][0], HW[l][1], hc2);
-    const int u3 = b.tensor(HW[l][0], HW[l][1], hc3);
-    const int u4 = b.tensor(HW[l][0], HW[l][1], hc4);
-    add_conv_op({l_cv2[l][1]}, Slice{hcat, 0, hc2}, Slice{u2, 0, hc2}, 0, 0, 0);
-    add_conv_op({l_cv3[l][1]}, Slice{hcat, hc2, hc3}, Slice{u3, 0, hc3}, 0, 0, 0);
-    add_conv_op({l_cv4[l][1]}, Slice{hcat, hc2 + hc3, hc4}, Slice{u4, 0, hc4}, 0, 0, 0);
-    add_conv_op({l_cv2[l][2]}, Slice{u2, 0, hc2}, Slice{-1, 0, 64}, 1, 0, lvl_off[l]);
-    add_conv_op({l_cv3[l][2]}, Slice{u3, 0, hc3}, Slice{-1, 0, nc}, 1, 64, lvl_off[l]);
-    add_conv_op({l_cv4[l][2]}, Slice{u4, 0, hc4}, Slice{-1, 0, nm}, 1, 64 + nc, lvl_off[l]);
+    // the three second convs write side by side into one tensor, so that the three 1x1 output convs (64 box bins,
+    // nc classes, nm mask coefficients: different inputs) run as ONE launch with a block-diagonal weight matrix and
+    // write a whole row of the raw head map
+    const int ucat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
+    add_conv_op({l_cv2[l][1]}, Slice{hcat, 0, hc2}, Slice{ucat, 0, hc2}, 0, 0, 0);
+    add_conv_op({l_cv3[l][1]}, Slice{hcat, hc2, hc3}, Slice{ucat, hc2, hc3}, 0, 0, 0);
+    add_conv_op({l_cv4[l][1]}, Slice{hcat, hc2 + hc3, hc4}, Slice{ucat, hc2 + hc3, hc4}, 0, 0, 0);
+    {
+      Op op{};
+      op.kind = OP_CONV;
+      op.conv = b.phys_diag({l_cv2[l][2], l_cv3[l][2], l_cv4[l][2]});
+      op.in = Slice{ucat, 0, hc2 + hc3 + hc4};
+      op.out = Slice{-1, 0, 64 + nc + nm};
+      op.out_ext = 1; op.raw_off = 0; op.level_off = lvl_off[l];
+      b.add_macs(op, e->phys[op.conv]);
+      e->ops.push_back(op);
+    }
   }
   {
     const int pr1 = b.tensor(H3, W3, npr), pr2 = b.tensor(H2, W2, npr), pr3 = b.tensor(H2, W2, npr);
@@ -424,7 +458,7 @@ void annotate_ops(m355_engine* e) {
         } else {
           Ho = (ti.H + 2 * (p.k / 2) - p.k) / p.stride + 1;
           Wo = (ti.W + 2 * (p.k / 2) - p.k) / p.stride + 1;
-          op.flops = 2.0 * Ho * Wo * p.cout * p.cin * p.k * p.k;
+          op.flops = 2.0 * Ho * Wo * p.macs_px;
         }
         op.tile = conv_pick_tile(cout_v, e->desc.max_batch * Ho * Wo);
         if (k == 1 && op.tile == TILE_128x128 && getenv("M355_K1_TILE")) op.tile = atoi(getenv("M355_K1_TILE"));
@@ -473,12 +507,12 @@ void annotate_ops(m355_engine* e) {
 }
 
 // Pack fp32 (cout,cin,k,k) -> fp16 rows [row0+co][ (kh*k+kw)*cin + ci ] of a [cout_pad][Kpad] matrix.
-void pack_conv_rows(const float* w, int cout, int cin, int k, int Kpad, int row0, std::vector<half_t>& dst) {
+void pack_conv_rows(const float* w, int cout, int cin, int k, int Kpad, int row0, std::vector<half_t>& dst, int koff = 0) {
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int kh = 0; kh < k; ++kh)
         for (int kw = 0; kw < k; ++kw)
-          dst[(size_t)(row0 + co) * Kpad + (kh * k + kw) * cin + ci] =
+          dst[(size_t)(row0 + co) * Kpad + koff + (kh * k + kw) * cin + ci] =
               (half_t)w[(((size_t)co * cin + ci) * k + kh) * k + kw];
 }
 
@@ -586,7 +620,7 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     HIP_TRY(e, hipMemcpy(p.bias, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
   } else {
     std::vector<half_t> rows((size_t)ci.cout * p.Kpad, (half_t)0.f);
-    pack_conv_rows(w, ci.cout, ci.cin, ci.k, p.Kpad, 0, rows);
+    pack_conv_rows(w, ci.cout, ci.cin, ci.k, p.Kpad, 0, rows, p.diag ? e->conv_phys_koff[idx] : 0);
     HIP_TRY(e, hipMemcpy(p.w + (size_t)row0 * p.Kpad, rows.data(), rows.size() * sizeof(half_t),
                          hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias + row0, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
