@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-op HIP events")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of overlapping it with the next batch")
-    ap.add_argument("--profile-every", type=int, default=5,
+    ap.add_argument("--profile-every", type=int, default=10,
                     help="record per-op HIP events on every n-th timed step (an event pair per launch costs "
                          "~8 us of serialisation, ~0.6 ms per fully instrumented step)")
     args = ap.parse_args()
