@@ -182,30 +182,48 @@ __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
   return r;
 }
 
+// CG 8-channel groups (CG * 16 bytes of a pixel) per block: consecutive lanes take consecutive groups of one pixel, so
+// a wave's loads / stores are runs of CG * 16 contiguous bytes.  Each 5x5 max is separable: a row pass into a scratch
+// plane, then a column pass; window indices are clamped (duplicates do not change a max), so both passes are five
+// unconditional LDS reads that the compiler unrolls and overlaps.
+template <int CG>
 __global__ __launch_bounds__(256) void sppf_pool_kernel(const half_t* x, long x_bstride, int ldx, half_t* y,
                                                         long y_bstride, int ldy, int H, int W, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  half8* p0 = (half8*)smem;
-  half8* p1 = p0 + H * W;
-  const int groups = C / 8;
-  const int b = blockIdx.x / groups, gq = blockIdx.x % groups;
-  const half_t* xb = x + (long)b * x_bstride + gq * 8;
-  half_t* yb = y + (long)b * y_bstride + gq * 8;
-  const int n = H * W;
-  for (int i = threadIdx.x; i < n; i += 256) p0[i] = *(const half8*)(xb + (long)i * ldx);
+  const int n = H * W * CG;
+  half8* src = (half8*)smem;
+  half8* tmp = src + n;
+  half8* dst = tmp + n;
+  const int chunks = C / (8 * CG);
+  const int b = blockIdx.x / chunks, gq = blockIdx.x % chunks;
+  const half_t* xb = x + (long)b * x_bstride + gq * 8 * CG;
+  half_t* yb = y + (long)b * y_bstride + gq * 8 * CG;
+  for (int i = threadIdx.x; i < n; i += 256) src[i] = *(const half8*)(xb + (long)(i / CG) * ldx + (i % CG) * 8);
   __syncthreads();
-  half8* src = p0;
-  half8* dst = p1;
   for (int lvl = 0; lvl < 3; ++lvl) {
     for (int i = threadIdx.x; i < n; i += 256) {
-      const int h = i / W, w = i - h * W;
-      const int h0 = h - 2 < 0 ? 0 : h - 2, h1 = h + 2 >= H ? H - 1 : h + 2;
-      const int w0 = w - 2 < 0 ? 0 : w - 2, w1 = w + 2 >= W ? W - 1 : w + 2;
-      half8 m = src[h0 * W + w0];
-      for (int hh = h0; hh <= h1; ++hh)
-        for (int ww = w0; ww <= w1; ++ww) m = hmax8(m, src[hh * W + ww]);
+      const int px = i / CG, cgi = i - px * CG;
+      const int h = px / W, w = px - h * W;
+      half8 m = src[i];
+#pragma unroll
+      for (int d = -2; d <= 2; ++d) {
+        const int ww = w + d < 0 ? 0 : (w + d >= W ? W - 1 : w + d);
+        m = hmax8(m, src[(h * W + ww) * CG + cgi]);
+      }
+      tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const int px = i / CG, cgi = i - px * CG;
+      const int h = px / W, w = px - h * W;
+      half8 m = tmp[i];
+#pragma unroll
+      for (int d = -2; d <= 2; ++d) {
+        const int hh = h + d < 0 ? 0 : (h + d >= H ? H - 1 : h + d);
+        m = hmax8(m, tmp[(hh * W + w) * CG + cgi]);
+      }
       dst[i] = m;
-      *(half8*)(yb + (long)i * ldy + lvl * C) = m;
+      *(half8*)(yb + (long)px * ldy + lvl * C + cgi * 8) = m;
     }
     __syncthreads();
     half8* t = src;
@@ -353,15 +371,17 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
 int launch_sppf_pool(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy, int B, int H,
                      int W, int C, hipStream_t s) {
   if (C % 8 || ldx % 8 || ldy % 8) return -1;
-  const size_t lds = (size_t)2 * H * W * 16;
+  // widest channel chunk per block that still leaves >= 256 blocks and fits the LDS
+  int cg = 4;
+  while (cg > 1 && ((C / 8) % cg != 0 || (long)B * (C / (8 * cg)) < 512 || (size_t)3 * H * W * 16 * cg > 160 * 1024)) cg >>= 1;
+  const size_t lds = (size_t)3 * H * W * 16 * cg;
   if (lds > 160 * 1024) return -1;
+  auto k = cg == 4 ? sppf_pool_kernel<4> : (cg == 2 ? sppf_pool_kernel<2> : sppf_pool_kernel<1>);
   if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute((const void*)sppf_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(sppf_pool_kernel, dim3(B * (C / 8)), dim3(256), lds, s, x, x_bstride, ldx, y, y_bstride, ldy,
-                     H, W, C);
+  hipLaunchKernelGGL(k, dim3(B * (C / (8 * cg))), dim3(256), lds, s, x, x_bstride, ldx, y, y_bstride, ldy, H, W, C);
   return (int)hipGetLastError();
 }
 
