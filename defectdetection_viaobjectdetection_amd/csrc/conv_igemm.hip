@@ -376,9 +376,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
         }
         if (a.out_f32) {
           float* yp = (float*)a.y + yoff;
+          const int lim = (a.convt_co > 0) ? a.convt_co : a.Cout;
+          if (cidx + GW <= lim) {   // whole group inside: 16-byte stores (rows of the raw head map are only 4-byte aligned)
+            typedef float float4u __attribute__((ext_vector_type(4), aligned(4)));
+            *(float4u*)yp = float4u{v[0], v[1], v[2], v[3]};
+            if (GW == 8) *(float4u*)(yp + 4) = float4u{v[GW - 4], v[GW - 3], v[GW - 2], v[GW - 1]};
+          } else {
 #pragma unroll
-          for (int j = 0; j < GW; ++j)
-            if (cidx + j < ((a.convt_co > 0) ? a.convt_co : a.Cout)) yp[j] = v[j];
+            for (int j = 0; j < GW; ++j)
+              if (cidx + j < lim) yp[j] = v[j];
+          }
         } else {
           half_t* yp = (half_t*)a.y + yoff;
           if (GW == 8) {
