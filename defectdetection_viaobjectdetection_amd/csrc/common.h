@@ -155,6 +155,33 @@ __device__ __forceinline__ void conv_epilogue_fast(float4v (&acc)[MT][NT], const
     }
   }
 }
+// Same, with one output pointer per pixel tile (ConvTranspose pixel-shuffle stores: not affine in nt), no residual.
+template <int MT, int NT, bool ACT>
+__device__ __forceinline__ void conv_epilogue_fast_ptrs(float4v (&acc)[MT][NT], const float4v (&bias)[MT / 2][2],
+                                                        half_t* const (&yp)[NT]) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+    for (int s = 0; s < MT / 2; ++s) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v[j] = acc[2 * s][nt][j] + bias[s][0][j];
+        v[4 + j] = acc[2 * s + 1][nt][j] + bias[s][1][j];
+      }
+      if (ACT) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = m355_silu(v[j]);
+      }
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = m355_to_half(v[j]);
+      *(half8*)(yp[nt] + s * 32) = o;
+    }
+  }
+}
 #endif
+
 
 }  // namespace m355

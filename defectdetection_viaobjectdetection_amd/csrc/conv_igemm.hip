@@ -291,9 +291,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     // is affine in the pixel index; the bias is fetched before the K loop and waits in registers.
     const bool fast = MT >= 2 && !a.out_f32 && a.convt_co == 0 && px_base + BPX <= a.M && ch_base + BCH <= a.Cout &&
                       a.y_bstride == (long)HoWo * a.ldy && (!a.res || a.r_bstride == (long)HoWo * a.ldr) && !(a.dbg & (32 | 256));
+    // ConvTranspose 2x2 / s2 (virtual channel q * Co + co, q = dy * 2 + dx): when a channel tile lies inside one q
+    // (Co a multiple of the tile) and the 16-pixel groups do not straddle image rows, (dy, dx) are uniform per block
+    // and each group's 16 pixels go to 16 output pixels two apart in one row
+    const bool fast_t = MT >= 2 && !a.out_f32 && a.convt_co > 0 && a.convt_co % BCH == 0 && a.Wo % 16 == 0 && !a.res &&
+                        px_base + BPX <= a.M && ch_base + BCH <= a.Cout && !(a.dbg & (32 | 256));
     float4v bv[MT >= 2 ? MT / 2 : 1][2];
-    if (fast) {
-      const float* bp = a.bias + ch_base + wch * MT * 16 + g * 8;
+    if (fast || fast_t) {
+      const int cb0 = fast_t ? ch_base % a.convt_co : ch_base;   // the bias is indexed by the real output channel
+      const float* bp = a.bias + cb0 + wch * MT * 16 + g * 8;
 #pragma unroll
       for (int sg = 0; sg < MT / 2; ++sg) {
         bv[sg][0] = *(const float4v*)(bp + sg * 32);
@@ -305,6 +311,22 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     if (a.stamps && tile == lb) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
+    if (MT >= 2 && fast_t) {
+      const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
+      const int co = ch_base - q * a.convt_co + wch * MT * 16 + g * 8;
+      half_t* yp[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int m = px_base + wpx * NT * 16 + nt * 16 + l15;
+        int bb, pix, ho, wo;
+        fast_divmod(m, HoWo, inv_howo, bb, pix);
+        fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+        yp[nt] = (half_t*)a.y + (long)bb * a.y_bstride + ((long)(2 * ho + dy) * (2 * a.Wo) + 2 * wo + dx) * a.ldy + co;
+      }
+      if (a.act) conv_epilogue_fast_ptrs<(MT >= 2 ? MT : 2), NT, true>(acc, bv, yp);
+      else conv_epilogue_fast_ptrs<(MT >= 2 ? MT : 2), NT, false>(acc, bv, yp);
+      continue;
+    }
     if (MT >= 2 && fast) {
       const long m0 = px_base + wpx * NT * 16 + l15;
       const int cho = ch_base + wch * MT * 16 + g * 8;

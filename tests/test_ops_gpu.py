@@ -120,9 +120,11 @@ def test_conv2d_f32_out_small_cout(cuda_device):
         assert rel_l2(y, y_ref) <= 1e-5
 
 
-def test_convt2x2(cuda_device):
+@pytest.mark.parametrize("shape", [(2, 20, 12, 128, 128), (2, 16, 32, 128, 128), (3, 8, 16, 64, 256), (1, 12, 16, 128, 48)])
+def test_convt2x2(shape, cuda_device):
+    """(W % 16 == 0 and Co % 128 == 0 take the fast pixel-shuffle epilogue, the others the generic one)"""
     capi = _lib()
-    B, H, W, cin, cout = 2, 20, 12, 128, 128
+    B, H, W, cin, cout = shape
     g = torch.Generator().manual_seed(5)
     x = torch.randn(B, cin, H, W, generator=g)
     w = torch.randn(cin, cout, 2, 2, generator=g) / cin ** 0.5
