@@ -447,7 +447,9 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   // network (fewer resident waves, epilogue-store drain on the next tile's first vmcnt(0)); it is kept
   // behind dbg bit 64 for experiments.
   int grid_x = tiles_ch * tiles_px;
-  if (a.dbg & 64) {
+  // measured again after the fast epilogue: neutral for the 128x128 tile, 7-20 % faster for 1x1 layers on the
+  // narrow channel tiles (proto.cv3 63 -> 51 us), so those run persistent
+  if ((a.dbg & 64) || (a.ksize == 1 && BCH <= 64 && !getenv("M355_NO_PERSIST"))) {
     int per_cu = (160 * 1024) / LDS;
     if (per_cu > 2) per_cu = 2;
     if (grid_x > g_num_cus * per_cu) grid_x = g_num_cus * per_cu;
@@ -485,6 +487,7 @@ int conv_pick_tile(int cout, long M) {
 int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   ConvArgs a = a0;
   if (getenv("M355_NO_FAST_EPI")) a.dbg |= 256;
+  if (getenv("M355_PERSIST") && (atoi(getenv("M355_PERSIST")) & (a.ksize == 1 ? 1 : 2))) a.dbg |= 64;
   if (a.ksize < 1 || a.ksize > 3) return -1;
   if (a.ksize == 2 && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // only the ConvT-dgrad form
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
