@@ -42,7 +42,7 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20 };
 
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s);
 // tile heuristic: cout = (virtual) output channels, M = output pixels of the whole batch
@@ -57,6 +57,9 @@ int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // vari
 // 128 ch x 16x16 px, K depth 32 per step (conv3x3_wide.hip)
 bool conv3x3_wide_ok(const ConvArgs& a);
 int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s);
+// Cin = Cout = 32, weights-stationary persistent halo kernel (conv3x3_c32.hip)
+bool conv3x3_c32_ok(const ConvArgs& a);
+int launch_conv3x3_c32(const ConvArgs& a, hipStream_t s);
 
 struct StemArgs {
   const uint8_t* x; int B, H, W;     // uint8 NHWC (B,H,W,3)

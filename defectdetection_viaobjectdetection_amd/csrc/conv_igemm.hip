@@ -98,6 +98,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
   const float inv_cin = 1.0f / (float)a.Cin;
   const float inv_tch = 1.0f / (float)tiles_ch;
 
+  const bool lin1 = KS == 1 && a.stride == 1 && a.pad == 0 && a.x_bstride == (long)HoWo * a.ldx;
   long rowoff[A_IT];        // element offset of (b, hi0, wi0, 0) for each of this lane's pixel rows
   unsigned rowmask[A_IT];   // bit t: tap t is inside the image (and the row is < M)
   const half_t* wsrc[W_IT]; // this lane's weight rows (+ chunk column)
@@ -114,6 +115,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
       const int m = px_base + prow;
       const bool mv = m < a.M;
       const int mm = mv ? m : 0;
+      if (KS == 1 && lin1) {   // 1x1 / stride 1 over contiguous images: the pixel index is the row index
+        rowoff[i] = (long)mm * a.ldx;
+        rowmask[i] = mv ? 1u : 0u;
+        continue;
+      }
       int b, pix, ho, wo;
       fast_divmod(mm, HoWo, inv_howo, b, pix);
       fast_divmod(pix, a.Wo, inv_wo, ho, wo);

@@ -471,8 +471,12 @@ void annotate_ops(m355_engine* e) {
           probe.ldx = 8; probe.ldy = 8;
           if (op.kind == OP_CONV && conv3x3_halo_ok(probe) && !getenv("M355_NO_HALO")) op.tile = TILE_HALO;
           wide = op.tile == TILE_HALO && conv3x3_wide_ok(probe) && !getenv("M355_NO_WIDE");
+          probe.Kpad = p.Kpad;
+          if (op.kind == OP_CONV && conv3x3_c32_ok(probe) && !getenv("M355_NO_C32")) op.tile = TILE_C32;
         }
-        if (wide)
+        if (op.tile == TILE_C32)
+          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c32<32ch,16x16px>");
+        else if (wide)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_wide<128ch,16x16px>");
         else if (op.tile == TILE_HALO)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_halo<%s>", cout_v > 64 ? "128ch" : "64ch");
@@ -696,7 +700,8 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           a.res = tr.p + op.res.off; a.r_bstride = (long)tr.H * tr.W * tr.C; a.ldr = tr.C;
         }
         a.M = B * a.Ho * a.Wo;
-        rc = (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s) : launch_conv_igemm(a, op.tile, s);
+        rc = (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
+             : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s) : launch_conv_igemm(a, op.tile, s));
         break;
       }
       case OP_POOL: {
@@ -863,8 +868,10 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   }
   int rc = 0;
   for (int rep = 0; rep < (a.dbg ? 5 : 1); ++rep)
-    rc = (force_tile >= 0 && (force_tile & 0xff) >= TILE_HALO) ? launch_conv3x3_halo(a, (force_tile & 0xff) - TILE_HALO, s)
-                                                              : launch_conv_igemm(a, force_tile, s);
+    rc = (force_tile >= 0 && (force_tile & 0xff) == TILE_C32)
+             ? launch_conv3x3_c32(a, s)
+             : ((force_tile >= 0 && (force_tile & 0xff) >= TILE_HALO) ? launch_conv3x3_halo(a, (force_tile & 0xff) - TILE_HALO, s)
+                                                                       : launch_conv_igemm(a, force_tile, s));
   hipError_t se = hipStreamSynchronize(s);
   if (st_path && se == hipSuccess) {
     std::vector<unsigned long long> h(st_n);

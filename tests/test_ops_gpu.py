@@ -68,6 +68,10 @@ CONV_CASES = [
     (2, 72, 56, 64, 128, 3, 1, 1, True, 19),        # 2 chunks, partial spatial tiles
     (1, 160, 160, 128, 128, 3, 1, 1, False, 19),
     (3, 48, 32, 192, 256, 3, 1, 0, False, 19),      # 6 chunks, two channel tiles, no act
+    # narrow weights-stationary kernel (20): Cin = Cout = 32
+    (2, 32, 32, 32, 32, 3, 1, 1, True, 20),         # residual, full tiles
+    (3, 72, 56, 32, 32, 3, 1, 1, False, 20),        # partial spatial tiles
+    (1, 160, 160, 32, 32, 3, 1, 0, False, 20),      # several tiles per block is exercised by the engine tests; no act
 ]
 
 
