@@ -98,11 +98,20 @@ class YOLO:
         self._drop_engines()
 
     def _load_checkpoint(self, path: str) -> None:
-        ck = torch.load(path, map_location="cpu", weights_only=False)
+        ck = None
+        try:
+            ck = torch.load(path, map_location="cpu", weights_only=True)
+        except Exception:  # noqa: BLE001 -- not one of ours (or not loadable without class definitions)
+            ck = None
         if not isinstance(ck, dict) or ck.get("format") != CKPT_FORMAT:
-            raise ValueError(
-                f"{path} is not a {CKPT_FORMAT} checkpoint.  Upstream-pickled .pt files reference ultralytics classes "
-                "that are unavailable offline (SURVEY.md H4 / next row N3).")
+            # a checkpoint written by upstream Ultralytics: recover the tensors without its classes (upstream_ckpt.py)
+            from .upstream_ckpt import load_upstream_checkpoint
+            up = load_upstream_checkpoint(path)
+            self.scale, self.nc, self.names = up["scale"], up["nc"], up["names"]
+            self.train_args = up["train_args"]
+            self.state_dict = up["state_dict"]
+            self.ckpt_path = path
+            return
         self.scale, self.nc = ck["scale"], int(ck["nc"])
         self.names = {int(k): v for k, v in ck["names"].items()}
         self.train_args = ck.get("train_args", {})
