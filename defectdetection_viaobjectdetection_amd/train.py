@@ -235,12 +235,21 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dev_index = devices[local_rank] if world > 1 and len(devices) == world else (local_rank if world > 1 else devices[0])
+    # Rehearsal on a one-GPU box: every rank on the same device and gloo as the transport (RCCL refuses two ranks on
+    # one GPU).  Everything else -- batch sharding, bucketed all-reduce under backward, rank-0 bookkeeping -- is the
+    # production path.
+    backend = os.environ.get("M355_DIST_BACKEND", "nccl")
+    if os.environ.get("M355_DIST_SAME_DEVICE"):
+        dev_index = devices[0]
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     own_pg = False
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)  # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         own_pg = True
     if batch % world:
         raise ValueError(f"batch {batch} must be a multiple of the number of GPUs {world}")

@@ -139,3 +139,27 @@ def test_train_rejects_unknown_kwargs_and_missing_data(tmp_path):
         model.train(data="x.yaml", epochs=1, not_a_real_option=3)
     with pytest.raises(FileNotFoundError):
         model.train(data=str(tmp_path / "missing.yaml"), epochs=1, imgsz=160, batch=2)
+
+
+def test_two_rank_training_rehearsal_on_one_gpu(tmp_path):
+    """The N > 1 training path end to end: two processes launched by torch.distributed.run share this box's one GPU
+    (gloo transport, since RCCL refuses two ranks per device); each takes half of every global batch, gradients are
+    summed in buckets under backward, rank 0 validates and writes the run directory."""
+    import subprocess
+    import sys
+    data = make_defect_dataset(str(tmp_path / "data-seg"), n_train=16, n_val=4)
+    run = tmp_path / "runs"
+    script = tmp_path / "ddp_train.py"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script.write_text(
+        f"import sys\nsys.path.insert(0, {root!r})\nfrom ultralytics import YOLO\n"
+        f"m = YOLO('yolov8n-seg.yaml')\n"
+        f"r = m.train(data={data!r}, epochs=3, imgsz=160, batch=8, project={str(run)!r}, name='ddp', device=0, warmup_epochs=1.0, verbose=False, bucket_mb=1)\n"
+        f"import os\nprint('RANK', os.environ['RANK'], 'steps', r.optimizer_steps, 'loss', sum(r.history[-1][k] for k in r.history[-1] if k.startswith('train/')) if r.history else -1)\n")
+    env = dict(os.environ, M355_DIST_BACKEND="gloo", M355_DIST_SAME_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+                          "127.0.0.1", "--master-port", "29533", str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "RANK 0" in out.stdout and "RANK 1" in out.stdout
+    for f in ("weights/last.pt", "weights/best.pt", "results.csv"):
+        assert os.path.isfile(os.path.join(str(run), "ddp", f)), f
