@@ -31,6 +31,12 @@ class OpInfo(C.Structure):
                 ("bytes_per_image", C.c_double), ("weight_bytes", C.c_double)]
 
 
+class AugParams(C.Structure):
+    """m355_aug_params (include/mi355yolo.h)."""
+    _fields_ = [("src", C.c_int32 * 4), ("xc", C.c_float), ("yc", C.c_float), ("minv", C.c_float * 6),
+                ("hgain", C.c_float), ("sgain", C.c_float), ("vgain", C.c_float), ("flip", C.c_int32), ("mosaic", C.c_int32)]
+
+
 class ConvLaunchArgs(C.Structure):
     """m355_conv_args (include/mi355yolo.h)."""
     _fields_ = [("x", C.c_void_p), ("x_bstride", C.c_int64), ("ldx", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32),
@@ -97,6 +103,7 @@ SIGNATURES = {
     "m355_sgd_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float,
                                 C.c_float, C.c_float, _P]),
     "m355_grad_sumsq": (C.c_int, [_P, C.c_int64, _P, _P]),
+    "m355_augment": (C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P]),
     "m355_sppf_pool_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, _P]),
     "m355_upsample2x_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

@@ -96,6 +96,8 @@ int launch_adamw_step(float* p, const float* g, float* m, float* v, float* ema, 
 int launch_sgd_step(float* p, const float* g, float* buf, float* ema, const unsigned char* group, long n, float lr,
                     float lr_bias, float momentum, int nesterov, float wd, float grad_mul, float ema_d, hipStream_t s);
 int launch_grad_sumsq(const float* g, long n, float* out, hipStream_t s);
+// mosaic + affine + HSV + flip gather (augment.hip); params: device array of B m355_aug_params
+int launch_augment(const uint8_t* cache, const void* params, uint8_t* out, int B, int H, int W, hipStream_t s);
 int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int ldz, int lddy, int C, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, float* rsum, half_t* dz,
                              int lddz, int act, hipStream_t s);

@@ -1111,6 +1111,12 @@ int m355_sgd_step(float* p, const float* g, float* momentum_buf, float* ema, con
 int m355_grad_sumsq(const float* g, int64_t n, float* out, void* stream) {
   return m355::launch_grad_sumsq(g, n, out, (hipStream_t)stream);
 }
+int m355_augment(const void* d_cache, const m355_aug_params* d_params, void* d_out, int32_t B, int32_t H, int32_t W,
+                 void* stream) {
+  if (!d_cache || !d_params || !d_out) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = m355::launch_augment((const uint8_t*)d_cache, d_params, (uint8_t*)d_out, B, H, W, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "augment launch failed: " + std::to_string(rc));
+}
 int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

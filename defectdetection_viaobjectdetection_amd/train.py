@@ -11,8 +11,8 @@ in buckets overlapped with backward (N > 1 only) -> one fused optimizer + EMA ke
 fp16 activations / gradients with a dynamic loss scale play the role of upstream's AMP GradScaler.  There is no CPU
 path: without a GPU and ``libmi355yolo.so`` this raises.
 
-Not built (next rows N2/N3): mosaic / affine / HSV augmentation (left-right flip only), resume, early-stopping
-``patience``, plots.
+Augmentation (mosaic, scale / translate affine, HSV, flip) is one GPU gather kernel over the HBM-resident image cache
+(``augment.py`` / ``csrc/augment.hip``).  Not built (next row N3): resume, early-stopping ``patience``, plots.
 """
 from __future__ import annotations
 
@@ -37,7 +37,8 @@ from .sharding import GradBucketReducer
 DEFAULTS = dict(optimizer="auto", lr0=0.01, lrf=0.01, momentum=0.937, weight_decay=5e-4, warmup_epochs=3.0,
                 warmup_momentum=0.8, warmup_bias_lr=0.1, nbs=64, seed=0, fliplr=0.5, val=True, exist_ok=False,
                 box=7.5, cls=0.5, dfl=1.5, conf=0.001, iou=0.7, max_det=300, workers=8, patience=100, amp=True,
-                verbose=True, save=True, bucket_mb=32)
+                verbose=True, save=True, bucket_mb=32, augment=True, mosaic=1.0, scale=0.5, translate=0.1, hsv_h=0.015,
+                hsv_s=0.7, hsv_v=0.4, close_mosaic=10)
 EMA_DECAY, EMA_TAU = 0.9999, 2000.0
 GRAD_CLIP = 10.0
 
@@ -300,6 +301,11 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
     model.train_args = dict(data=os.path.abspath(data), epochs=epochs, imgsz=imgsz, batch=batch, optimizer=opt_name, lr0=lr0,
                             momentum=momentum, weight_decay=weight_decay, seed=a.seed)
     validator = Validator(val_ds, model.scale, model.nc, dev_index, 16, a.conf, a.iou, a.max_det) if val_ds is not None else None
+    augmenter = None
+    if a.augment:
+        from .augment import Augmenter
+        augmenter = Augmenter(train_ds, dev, seed=a.seed + 1000 * rank, mosaic=a.mosaic, scale=a.scale, translate=a.translate,
+                              hsv_h=a.hsv_h, hsv_s=a.hsv_s, hsv_v=a.hsv_v, fliplr=a.fliplr)
     scaler = LossScaler()
     rng = np.random.default_rng(a.seed + 1000 * rank)
     st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
@@ -334,8 +340,12 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
                 lr = f * lr0 * lf
                 lr_bias = warmup_bias_lr + f * (lr0 * lf - warmup_bias_lr)
                 mom = a.warmup_momentum + f * (momentum - a.warmup_momentum) if opt_name == "sgd" else momentum
-            b = train_ds.batch(idx, flip=rng.random(len(idx)) < a.fliplr)
-            imgs = torch.from_numpy(b["img"]).to(dev, non_blocking=True)
+            if augmenter is not None:     # mosaic / affine / HSV / flip rendered by the GPU kernel from the HBM image cache
+                b = augmenter.batch(idx, mosaic_on=epoch < epochs - a.close_mosaic)
+                imgs = b["img"]
+            else:
+                b = train_ds.batch(idx, flip=rng.random(len(idx)) < a.fliplr)
+                imgs = torch.from_numpy(b["img"]).to(dev, non_blocking=True)
             labels = {k: torch.from_numpy(b[k]).to(dev) for k in ("batch_idx", "cls", "bboxes", "masks")}
             raw, protos = eng.forward(imgs)
             r = raw.detach().clone().requires_grad_(True)

@@ -221,6 +221,21 @@ int m355_sgd_step(float* p, const float* g, float* momentum_buf, float* ema, con
 /* out[0] = sum of squares of the finite entries of g, out[1] = number of non-finite entries (device floats). */
 int m355_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
 
+/* Training-time augmentation on the device image cache (replaces upstream's CPU Mosaic / RandomPerspective /
+ * RandomHSV / RandomFlip transforms run by dataloader workers under /root/reference/BscanBased/yolo_seg_train.py:12).
+ * cache: uint8 (N,H,W,3); out: uint8 (B,H,W,3); params: DEVICE array of B records.  The polygons are transformed by
+ * the caller with the forward matrix (host side, dataset.py). */
+typedef struct {
+  int32_t src[4];          /* cache indices: top-left, top-right, bottom-left, bottom-right of the mosaic */
+  float xc, yc;            /* mosaic centre on the 2W x 2H canvas */
+  float minv[6];           /* canvas (u, v) = [a b c; d e f] * (x, y, 1) for output pixel (x, y) */
+  float hgain, sgain, vgain;
+  int32_t flip;            /* 1: mirror the output left-right */
+  int32_t mosaic;          /* 0: single image src[0] at the canvas origin */
+} m355_aug_params;
+int m355_augment(const void* d_cache, const m355_aug_params* d_params, void* d_out, int32_t B, int32_t H, int32_t W,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif
