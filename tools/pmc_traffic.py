@@ -9,7 +9,8 @@ LABELS = {
     "conv_igemm_kernel<4, 4, 2, 2, 3>": "conv_igemm<128x128,k3>", "conv_igemm_kernel<4, 4, 2, 2, 1>": "conv_igemm<128x128,k1>",
     "conv_igemm_kernel<4, 2, 1, 4, 3>": "conv_igemm<64x128,k3>", "conv_igemm_kernel<4, 2, 1, 4, 1>": "conv_igemm<64x128,k1>",
     "conv_igemm_kernel<2, 4, 1, 4, 3>": "conv_igemm<32x256,k3>", "conv_igemm_kernel<2, 4, 1, 4, 1>": "conv_igemm<32x256,k1>",
-    "conv3x3_wide_kernel": "conv3x3_wide<128ch,16x16px>",
+    "conv3x3_wide_kernel": "conv3x3_wide<128ch,16x16px>", "conv3x3_c32_kernel": "conv3x3_c32<32ch,16x16px>",
+    "stem_rows_kernel": "stem_conv<k3s2,u8,mfma>", "augment_kernel": "augment",
     "stem_kernel": "stem_conv<k3s2,u8,mfma>", "head_decode_kernel": "head_decode", "sppf_pool_kernel": "sppf_pool",
     "upsample2x_kernel": "upsample2x", "nms_kernel": "nms", "proto_masks_kernel": "proto_masks",
 }
@@ -23,7 +24,7 @@ def label(name):
     for k, v in MANGLED.items():
         if k in name:
             return v
-    for k in ("conv3x3_wide", "sppf_pool", "upsample2x", "proto_masks", "nms_kernel", "head_decode", "stem_kernel"):
+    for k in ("conv3x3_wide", "conv3x3_c32", "stem_rows", "sppf_pool", "upsample2x", "proto_masks", "nms_kernel", "head_decode", "stem_kernel"):
         if k in name:
             return LABELS.get(k + "_kernel", LABELS.get(k, k))
     return None
