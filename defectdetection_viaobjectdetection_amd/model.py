@@ -117,6 +117,7 @@ class YOLO:
         self.train_args = ck.get("train_args", {})
         self.state_dict = ck["model"]
         self.ckpt_path = path
+        self._resume_state = ck.get("trainer")       # present in weights/last.pt: lets train(resume=True) continue
 
     def save(self, path: str) -> str:
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)

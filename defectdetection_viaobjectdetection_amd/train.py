@@ -12,7 +12,8 @@ fp16 activations / gradients with a dynamic loss scale play the role of upstream
 path: without a GPU and ``libmi355yolo.so`` this raises.
 
 Augmentation (mosaic, scale / translate affine, HSV, flip) is one GPU gather kernel over the HBM-resident image cache
-(``augment.py`` / ``csrc/augment.hip``).  Not built (next row N3): resume, early-stopping ``patience``, plots.
+(``augment.py`` / ``csrc/augment.hip``).  ``resume=True`` continues from ``weights/last.pt`` (optimizer, EMA, loss scale,
+history); ``patience`` stops early.  Not built: plots.
 """
 from __future__ import annotations
 
@@ -216,8 +217,15 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
     unknown = [k for k in kwargs if k not in DEFAULTS and k not in ("pretrained", "task", "mode", "model", "resume", "max_steps")]
     if unknown:
         raise TypeError(f"train() got unexpected keyword(s) {unknown}; known: {sorted(DEFAULTS)}")
+    resume_state = None
     if kwargs.get("resume"):
-        raise NotImplementedError("resume=True is not implemented (SURVEY.md next row N3)")
+        resume_state = getattr(model, "_resume_state", None)
+        if not resume_state:
+            raise ValueError("resume=True needs a model loaded from a weights/last.pt written by this trainer")
+        ra = model.train_args
+        data = data or ra.get("data")
+        epochs, imgsz, batch = int(ra.get("epochs", epochs)), int(ra.get("imgsz", imgsz)), int(ra.get("batch", batch))
+        kwargs = {**{k: v for k, v in ra.get("options", {}).items() if k in DEFAULTS}, **{k: v for k, v in kwargs.items() if k != "resume"}}
     if not data:
         raise ValueError("train() needs data=<dataset yaml>")
     a = SimpleNamespace(**{**DEFAULTS, **{k: v for k, v in kwargs.items() if k in DEFAULTS}})
@@ -294,12 +302,13 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
     nw = max(round(a.warmup_epochs * nb), 100) if a.warmup_epochs > 0 else -1
     max_steps = kwargs.get("max_steps")
 
-    save_dir = _run_dir(project, name, a.exist_ok or world > 1)
+    save_dir = resume_state["save_dir"] if resume_state else _run_dir(project, name, a.exist_ok or world > 1)
     wdir = os.path.join(save_dir, "weights")
     if rank == 0:
         os.makedirs(wdir, exist_ok=True)
     model.train_args = dict(data=os.path.abspath(data), epochs=epochs, imgsz=imgsz, batch=batch, optimizer=opt_name, lr0=lr0,
-                            momentum=momentum, weight_decay=weight_decay, seed=a.seed)
+                            momentum=momentum, weight_decay=weight_decay, seed=a.seed,
+                            options={k: getattr(a, k) for k in DEFAULTS if isinstance(getattr(a, k), (int, float, str, bool))})
     validator = Validator(val_ds, model.scale, model.nc, dev_index, 16, a.conf, a.iou, a.max_det) if val_ds is not None else None
     augmenter = None
     if a.augment:
@@ -320,12 +329,32 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
         print(f"train: yolov8{model.scale}-seg nc={model.nc} imgsz={imgsz} batch={batch} (x{world} GPU, {local_batch}/GPU) "
               f"{len(train_ds)} images, {nb} it/epoch, optimizer={opt_name} lr0={lr0} wd={weight_decay:g} accumulate={accumulate}")
 
-    def ckpt(path: str, sd: Dict[str, torch.Tensor], epoch: int) -> None:
-        torch.save({"format": "mi355yolo-seg-v1", "scale": model.scale, "nc": model.nc, "names": model.names,
-                    "train_args": model.train_args, "model": sd, "epoch": epoch, "metrics": last_res}, path)
+    best_epoch, start_epoch = -1, 0
+    if resume_state:                                   # optimizer / EMA / scaler state of the interrupted run
+        flat_p.copy_(resume_state["flat_params"].to(dev))
+        ema.copy_(resume_state["ema"].to(dev))
+        state1.copy_(resume_state["state1"].to(dev))
+        state2.copy_(resume_state["state2"].to(dev))
+        eng.repack()
+        opt_steps, updates = int(resume_state["opt_steps"]), int(resume_state["updates"])
+        scaler.scale = float(resume_state["loss_scale"])
+        best_fit, best_epoch = float(resume_state["best_fit"]), int(resume_state["best_epoch"])
+        rows = list(resume_state["rows"])
+        start_epoch = int(resume_state["epoch"])
+        if rank == 0 and a.verbose:
+            print(f"resuming {save_dir} from epoch {start_epoch + 1}/{epochs}")
+
+    def ckpt(path: str, sd: Dict[str, torch.Tensor], epoch: int, with_trainer: bool = False) -> None:
+        ck = {"format": "mi355yolo-seg-v1", "scale": model.scale, "nc": model.nc, "names": model.names,
+              "train_args": model.train_args, "model": sd, "epoch": epoch, "metrics": last_res}
+        if with_trainer:                               # what resume=True needs (last.pt only)
+            ck["trainer"] = {"epoch": epoch, "flat_params": flat_p.cpu(), "ema": ema.cpu(), "state1": state1.cpu(),
+                             "state2": state2.cpu(), "opt_steps": opt_steps, "updates": updates, "loss_scale": scaler.scale,
+                             "best_fit": best_fit, "best_epoch": best_epoch, "rows": rows, "save_dir": save_dir}
+        torch.save(ck, path)
 
     stop = False
-    for epoch in range(epochs):
+    for epoch in range(start_epoch, epochs):
         lf = lr_factor(epoch, epochs, a.lrf)
         lr = lr_bias = lr0 * lf
         mom = momentum
@@ -413,11 +442,16 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
                     w.writeheader()
                     for rr in rows:
                         w.writerow({k: (f"{v:.5g}" if isinstance(v, float) else v) for k, v in rr.items()})
-                ckpt(os.path.join(wdir, "last.pt"), sd, epoch + 1)
                 fit = last_res.get("fitness", -mloss[0] - mloss[1] - mloss[2] - mloss[3])
-                if fit > best_fit or not os.path.isfile(os.path.join(wdir, "best.pt")):
-                    best_fit = max(fit, best_fit)
+                improved = fit > best_fit or not os.path.isfile(os.path.join(wdir, "best.pt"))
+                if improved:
+                    best_fit, best_epoch = max(fit, best_fit), epoch
                     ckpt(os.path.join(wdir, "best.pt"), sd, epoch + 1)
+                ckpt(os.path.join(wdir, "last.pt"), sd, epoch + 1, with_trainer=True)
+            if a.patience and best_epoch >= 0 and epoch - best_epoch >= a.patience:     # early stopping (A14: patience 100)
+                stop = True
+                if a.verbose:
+                    print(f"early stop: no fitness improvement for {a.patience} epochs (best epoch {best_epoch + 1})")
             if a.verbose:
                 msg = (f"epoch {epoch + 1}/{epochs}  box {mloss[0]:.4f} seg {mloss[1]:.4f} cls {mloss[2]:.4f} dfl {mloss[3]:.4f}"
                        f"  lr {lr:.2e} scale {scaler.scale:g}")
@@ -425,7 +459,9 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
                     msg += f"  mAP50(B) {last_res['metrics/mAP50(B)']:.4f} mAP50(M) {last_res['metrics/mAP50(M)']:.4f}"
                 print(msg, flush=True)
         if world > 1:
-            dist.barrier()
+            flag = torch.tensor([1 if stop else 0], device=dev)
+            dist.broadcast(flag, src=0)                # rank 0 decides (it owns the validator)
+            stop = bool(int(flag.item()))
         if stop:
             break
     if validator is not None:

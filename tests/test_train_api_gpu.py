@@ -163,3 +163,22 @@ def test_two_rank_training_rehearsal_on_one_gpu(tmp_path):
     assert "RANK 0" in out.stdout and "RANK 1" in out.stdout
     for f in ("weights/last.pt", "weights/best.pt", "results.csv"):
         assert os.path.isfile(os.path.join(str(run), "ddp", f)), f
+
+
+def test_resume_and_early_stopping(tmp_path):
+    from ultralytics import YOLO
+    data = make_defect_dataset(str(tmp_path / "data-seg"), n_train=16, n_val=4)
+    model = YOLO("yolov8n-seg.yaml")
+    r1 = model.train(data=data, epochs=5, imgsz=160, batch=8, project=str(tmp_path / "runs"), name="r", device=0,
+                     warmup_epochs=1.0, verbose=False, max_steps=4)        # 2 it/epoch: interrupted after epoch 2
+    run = str(tmp_path / "runs" / "r")
+    assert len(r1.history) == 2
+    again = YOLO(os.path.join(run, "weights", "last.pt"))
+    r2 = again.train(resume=True, verbose=False)
+    assert r2.save_dir == run and [h["epoch"] for h in r2.history] == [1, 2, 3, 4, 5]
+    assert r2.optimizer_steps > r1.optimizer_steps
+    # patience: fitness cannot improve on an unlearnable 1-epoch budget with patience 1 -> stops long before 50 epochs
+    m3 = YOLO("yolov8n-seg.yaml")
+    r3 = m3.train(data=data, epochs=50, imgsz=160, batch=8, project=str(tmp_path / "runs"), name="p", device=0,
+                  warmup_epochs=1.0, verbose=False, patience=2, lr0=0.0, optimizer="SGD")
+    assert len(r3.history) <= 6
