@@ -42,7 +42,7 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20 };
 
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s);
 // tile heuristic: cout = (virtual) output channels, M = output pixels of the whole batch

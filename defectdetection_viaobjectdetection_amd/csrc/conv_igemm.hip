@@ -52,14 +52,16 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, i
 
 // MT/NT: 16x16 MFMA tiles per wave along channels / pixels.  WCH/WPX: waves along channels / pixels.
 template <int MT, int NT, int WCH, int WPX, int KS>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
-  static_assert(WCH * WPX == 4, "4 waves");
+__global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv_igemm_kernel(const ConvArgs a) {  // (threads, min waves per SIMD)
+  constexpr int NW = WCH * WPX;       // waves per workgroup: 4, or 8 (half-size wave tiles: four waves per SIMD with two
+                                      // workgroups per CU hide the ~100-cycle issue cost of each LDS-DMA piece)
+  static_assert(NW == 4 || NW == 8, "4 or 8 waves");
   constexpr int BCH = WCH * MT * 16;  // channel tile
   constexpr int BPX = WPX * NT * 16;  // pixel tile
   constexpr int ROWB = BK * 2;        // 128 bytes per LDS row
   constexpr int STAGE = (BCH + BPX) * ROWB;
-  constexpr int A_IT = BPX / 32;      // LDS-DMA instructions per wave per stage, activations
-  constexpr int W_IT = BCH / 32;      // weights
+  constexpr int A_IT = BPX / (NW * 8);  // LDS-DMA instructions per wave per stage, activations
+  constexpr int W_IT = BCH / (NW * 8);  // weights
   static_assert(W_IT >= 1 && A_IT >= 1, "tile too small");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const int px_base = tile_px * BPX, ch_base = tile_ch * BCH;
 #pragma clang loop unroll(full)
     for (int i = 0; i < A_IT; ++i) {
-      const int prow = wave * (BPX / 4) + i * 8 + lrow;
+      const int prow = wave * (BPX / NW) + i * 8 + lrow;
       const int m = px_base + prow;
       const bool mv = m < a.M;
       const int mm = mv ? m : 0;
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     // the SOURCE side; LDS rows stay in plain MFMA-tile order (conflict-free ds_read_b128).
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
-      const int R = wave * (BCH / 4) + i * 8 + lrow;
+      const int R = wave * (BCH / NW) + i * 8 + lrow;
       const int blk = R / (MT * 16), Rl = R % (MT * 16);
       const int mt = Rl >> 4, r = Rl & 15;
       int chl;
@@ -184,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     const bool skip_w = (a.dbg & 2) && ld_g > 1, skip_a = (a.dbg & 1) && ld_g > 1;
 #pragma unroll
     for (int i = 0; i < W_IT; ++i) {
-      if (!skip_w) glds16(wsrc[i] + t * BK, sb + (wave * (BCH / 4) + i * 8) * ROWB);
+      if (!skip_w) glds16(wsrc[i] + t * BK, sb + (wave * (BCH / NW) + i * 8) * ROWB);
     }
     // activations: tap / cin of this lane's chunk at K step t
     const int kq = t * BK + cc * 8;
@@ -204,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs a) {
     for (int i = 0; i < A_IT; ++i) {
       const bool ok = (rowmask[i] >> tap) & 1u;
       const half_t* src = ok ? (a.x + rowoff[i] + tapoff) : a.zero;
-      if (!skip_a) glds16(src, ab + (wave * (BPX / 4) + i * 8) * ROWB);
+      if (!skip_a) glds16(src, ab + (wave * (BPX / NW) + i * 8) * ROWB);
     }
     ++ld_g;
     if (++ld_t == nk) {
@@ -460,7 +462,7 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
     if (per_cu > 2) per_cu = 2;
     if (grid_x > g_num_cus * per_cu) grid_x = g_num_cus * per_cu;
   }
-  const dim3 grid(grid_x), block(256);
+  const dim3 grid(grid_x), block(WCH * WPX * 64);
   hipError_t e;
   auto k1 = conv_igemm_kernel<MT, NT, WCH, WPX, 1>;
   auto k2 = conv_igemm_kernel<MT, NT, WCH, WPX, 2>;
@@ -506,6 +508,9 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
     case TILE_64x128: return launch_variant<4, 2, 1, 4>(a, s);
     case TILE_32x256: return launch_variant<2, 4, 1, 4>(a, s);
     case TILE_64x256: return launch_variant<4, 4, 1, 4>(a, s);
+    // 8 waves x (32 ch x 32 px), four waves per SIMD: measured equal to the 4-wave tiles on every layer class
+    // (tools/tile_sweep.py: the 1x1 layers run at 4.6 TB/s in isolation whatever the tile); kept for experiments
+    case TILE_64x128W8: return launch_variant<2, 2, 2, 4>(a, s);
     default: return -1;
   }
 }

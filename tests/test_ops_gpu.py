@@ -47,6 +47,11 @@ CONV_CASES = [
     (2, 20, 20, 128, 128, 3, 1, 1, False, 3),       # forced 64x256 tile
     (2, 20, 20, 64, 64, 1, 1, 0, False, 0),         # forced 128x128 tile with Cout=64
     (4, 80, 80, 128, 128, 3, 1, 1, True, -1),       # many tiles
+    # 8-wave im2col tile (5: 64 ch x 128 px, 8 waves)
+    (2, 24, 16, 128, 128, 3, 1, 1, True, 5),
+    (1, 17, 23, 64, 128, 3, 2, 1, False, 5),
+    (2, 20, 20, 256, 64, 3, 1, 1, True, 5),
+    (2, 16, 16, 48, 48, 1, 1, 0, False, 5),
     # halo-tile 3x3 kernel (tile id 16)
     (2, 32, 32, 64, 64, 3, 1, 1, False, 16),        # single chunk, 64-ch variant
     (2, 32, 48, 64, 64, 3, 1, 1, True, 16),
