@@ -39,6 +39,12 @@ struct ConvArgs {
   int tmode;           // 1: transposed-stride gather = dgrad of a 3x3 / stride-2 / pad-1 conv (x is dY, y is dX)
   int dbg;             // ablation switches for profiling experiments (0 in production)
   unsigned long long* stamps;  // diagnostic builds: per-block s_memtime stamps (nullptr in production)
+  // Upsample read-through (1x1 convs only): input channels [0, csplit) are NOT in x but in the half-resolution tensor
+  // x2 -- output pixel (h, w) reads x2 pixel (h >> 1, w >> 1), i.e. Upsample(2x, nearest) + Concat without the copy.
+  const half_t* x2;
+  long x2_bstride;
+  int ldx2;
+  int csplit;          // 0: off
 };
 
 // tile ids for launch_conv_igemm(force_tile)

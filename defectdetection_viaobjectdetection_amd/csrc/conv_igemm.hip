@@ -102,6 +102,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
 
   const bool lin1 = KS == 1 && a.stride == 1 && a.pad == 0 && a.x_bstride == (long)HoWo * a.ldx;
   long rowoff[A_IT];        // element offset of (b, hi0, wi0, 0) for each of this lane's pixel rows
+  long rowoff2[KS == 1 ? A_IT : 1];   // upsample read-through: element offset of (b, h >> 1, w >> 1, 0) in x2
   unsigned rowmask[A_IT];   // bit t: tap t is inside the image (and the row is < M)
   const half_t* wsrc[W_IT]; // this lane's weight rows (+ chunk column)
   int ld_tile = lb;         // loader cursor: tile, K step within the tile, global stage count
@@ -117,6 +118,12 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       const int m = px_base + prow;
       const bool mv = m < a.M;
       const int mm = mv ? m : 0;
+      if (KS == 1 && a.csplit > 0) {
+        int b2, pix2, ho2, wo2;
+        fast_divmod(mm, HoWo, inv_howo, b2, pix2);
+        fast_divmod(pix2, a.Wo, inv_wo, ho2, wo2);
+        rowoff2[KS == 1 ? i : 0] = (long)b2 * a.x2_bstride + ((long)(ho2 >> 1) * (a.Wo >> 1) + (wo2 >> 1)) * a.ldx2;
+      }
       if (KS == 1 && lin1) {   // 1x1 / stride 1 over contiguous images: the pixel index is the row index
         rowoff[i] = (long)mm * a.ldx;
         rowmask[i] = mv ? 1u : 0u;
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     for (int i = 0; i < A_IT; ++i) {
       const bool ok = (rowmask[i] >> tap) & 1u;
       const half_t* src = ok ? (a.x + rowoff[i] + tapoff) : a.zero;
+      if (KS == 1 && a.csplit > 0 && ok && kq < a.csplit) src = a.x2 + rowoff2[KS == 1 ? i : 0] + kq;
       if (!skip_a) glds16(src, ab + (wave * (BPX / NW) + i * 8) * ROWB);
     }
     ++ld_g;

@@ -45,6 +45,7 @@ struct Op {
   OpKind kind;
   int conv = -1;       // physical conv index (phys_)
   Slice in, out, res;  // tensor slices
+  Slice in2;           // upsample read-through: channels [0, in2.c) of `in` come from this half-resolution slice
   int out_ext = 0;     // 0: internal tensor; 1: raw head buffer (fp32, anchor offset); 2: protos (caller)
   int raw_off = 0;     // channel offset in raw buffer
   int level_off = 0;   // anchor offset of the level in the raw buffer
@@ -190,22 +191,22 @@ struct Builder {
     }
   }
   // Conv(+BN+SiLU) from slice `in` to slice `out`
-  void conv(const std::string& name, Slice in, Slice out, int k, int s, Slice res = Slice()) {
+  void conv(const std::string& name, Slice in, Slice out, int k, int s, Slice res = Slice(), Slice in2 = Slice()) {
     const int li = logical(name, in.c, out.c, k, s, 1, 0, 1);
     Op op{};
     op.kind = OP_CONV;
     op.conv = phys_from({li});
-    op.in = in; op.out = out; op.res = res;
+    op.in = in; op.out = out; op.res = res; op.in2 = in2;
     add_macs(op, e->phys[op.conv]);
     e->ops.push_back(op);
   }
   // C2f: in -> out
-  void c2f(const std::string& name, Slice in, Slice out, int n, bool shortcut) {
+  void c2f(const std::string& name, Slice in, Slice out, int n, bool shortcut, Slice up_src = Slice()) {
     const Tensor& ti = e->tensors[in.t];
     const int H = ti.H, W = ti.W;
     const int c = out.c / 2;
     const int cat = tensor(H, W, (2 + n) * c);
-    conv(name + ".cv1", in, Slice{cat, 0, 2 * c}, 1, 1);
+    conv(name + ".cv1", in, Slice{cat, 0, 2 * c}, 1, 1, Slice(), up_src);
     for (int j = 0; j < n; ++j) {
       const int tmp = tensor(H, W, c);
       const Slice src{cat, (1 + j) * c, c};
@@ -285,16 +286,19 @@ int build_graph(m355_engine* e) {
     e->ops.push_back(op);
     b.conv("model.9.cv2", Slice{sp, 0, 4 * c_}, x9, 1, 1);
   }
-  // 10/11: upsample x9 into cat11[0:c1024]
-  {
+  // 10/11: Upsample(x9) + Concat with x6.  By default nothing is copied: model.12.cv1 (1x1) reads channels
+  // [0, c1024) through its gather from the half-resolution x9 (upsample read-through, conv_igemm.hip); with
+  // M355_NO_UPFUSE the upsample kernel materialises them in cat11 instead.
+  const bool upfuse = !getenv("M355_NO_UPFUSE");
+  if (!upfuse) {
     Op op{};
     op.kind = OP_UP;
     op.in = x9;
     op.out = Slice{cat11, 0, c1024};
     e->ops.push_back(op);
   }
-  b.c2f("model.12", Slice{cat11, 0, c1024 + c512}, x12, b.rep(3), false);
-  {
+  b.c2f("model.12", Slice{cat11, 0, c1024 + c512}, x12, b.rep(3), false, upfuse ? x9 : Slice());
+  if (!upfuse) {
     Op op{};
     op.kind = OP_UP;
     op.in = x12;
@@ -302,7 +306,7 @@ int build_graph(m355_engine* e) {
     e->ops.push_back(op);
   }
   const int t15 = b.tensor(H3, W3, c256);
-  b.c2f("model.15", Slice{cat14, 0, c512 + c256}, Slice{t15, 0, c256}, b.rep(3), false);
+  b.c2f("model.15", Slice{cat14, 0, c512 + c256}, Slice{t15, 0, c256}, b.rep(3), false, upfuse ? x12 : Slice());
   b.conv("model.16", Slice{t15, 0, c256}, Slice{cat17, 0, c256}, 3, 2);
   const int t18 = b.tensor(H4, W4, c512);
   b.c2f("model.18", Slice{cat17, 0, c256 + c512}, Slice{t18, 0, c512}, b.rep(3), false);
@@ -484,6 +488,8 @@ void annotate_ops(m355_engine* e) {
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d>", tile_names[op.tile], k);
         op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)Ho * Wo * cout_v * (op.out_ext == 1 ? 4 : 2) +
                    (op.res.t >= 0 ? (double)Ho * Wo * cout_v * 2 : 0.0);
+        if (op.in2.t >= 0)   // the read-through part is a quarter-size tensor
+          op.bytes -= (double)ti.H * ti.W * op.in2.c * 2 * 0.75;
         op.wbytes = (double)p.cout_pad * p.Kpad * 2;
         break;
       }
@@ -694,6 +700,10 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           } else {
             a.y = d_protos; a.y_bstride = (long)e->proto_h * e->proto_w * e->nm; a.ldy = e->nm;
           }
+        }
+        if (op.in2.t >= 0) {
+          const Tensor& t2 = e->tensors[op.in2.t];
+          a.x2 = t2.p + op.in2.off; a.x2_bstride = (long)t2.H * t2.W * t2.C; a.ldx2 = t2.C; a.csplit = op.in2.c;
         }
         if (op.res.t >= 0) {
           const Tensor& tr = e->tensors[op.res.t];

@@ -134,3 +134,32 @@ def test_masks_parity(setup_s, cuda_device):
     frac = agree / total
     print(f"mask pixel agreement {frac:.6f} over {total} px")
     assert frac >= 0.995
+
+
+def test_upsample_read_through_equals_materialised_upsample(cuda_device):
+    """model.12.cv1 / model.15.cv1 read the upsampled half of their input through the gather (no upsample kernel);
+    with M355_NO_UPFUSE the upsample kernel writes it first.  Same bytes in, same bits out."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from helpers import synthetic_bscans
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(3, seed=11)[:, :320, :384].copy()).to(cuda_device)
+    outs = []
+    for fuse in (True, False):
+        if fuse:
+            os.environ.pop("M355_NO_UPFUSE", None)
+        else:
+            os.environ["M355_NO_UPFUSE"] = "1"
+        try:
+            eng = SegEngine("s", 1, (320, 384), max_batch=3)
+            kinds = [o["kernel"] for o in eng.op_infos()]
+            assert ("upsample2x" in kinds) == (not fuse)
+            eng.load_state_dict(sd)
+            p, q = eng.forward(imgs)
+            torch.cuda.synchronize()
+            outs.append((p.clone(), q.clone()))
+            eng.close()
+        finally:
+            os.environ.pop("M355_NO_UPFUSE", None)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
