@@ -45,6 +45,11 @@ struct ConvArgs {
   long x2_bstride;
   int ldx2;
   int csplit;          // 0: off
+  // Phase convolution (ksize 2, stride 1): the composition ConvTranspose(2x2, s2) -> Conv(3x3, s1, p1) is, for each of
+  // the four output phases (py, px), a 2x2 convolution over the LOW-resolution input with window rows h-1+py .. h+py
+  // (cols likewise).  Virtual channel q * convt_co + co, q = py * 2 + px, pixel-shuffle store like ConvTranspose; the
+  // bias is a [9][convt_co] table indexed by the output pixel's border class (first / interior / last row x column).
+  int phase;
 };
 
 // tile ids for launch_conv_igemm(force_tile)

@@ -133,8 +133,14 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       fast_divmod(mm, HoWo, inv_howo, b, pix);
       fast_divmod(pix, a.Wo, inv_wo, ho, wo);
       unsigned mk = 0;
-      const int hi0 = ho * a.stride - a.pad;
-      const int wi0 = wo * a.stride - a.pad;
+      int pad_y = a.pad, pad_x = a.pad;
+      if (KS == 2 && a.phase) {   // phase conv: the 2x2 window of phase (py, px) starts at (h - 1 + py, w - 1 + px)
+        const int q = ch_base / a.convt_co;
+        pad_y = 1 - (q >> 1);
+        pad_x = 1 - (q & 1);
+      }
+      const int hi0 = ho * a.stride - pad_y;
+      const int wi0 = wo * a.stride - pad_x;
       long off = (long)b * a.x_bstride + ((long)hi0 * a.Wi + wi0) * a.ldx;
       // NOTE: keep this loop body free of inner loops / continue: hipcc then fails to unroll the row loop for
       // A_IT = 8 and sends rowoff[] / rowmask[] to scratch (5x slower kernel).
@@ -327,6 +333,37 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     if (a.stamps && tile == lb) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
+    if (KS == 2 && MT >= 2 && a.phase) {   // phase conv: pixel-shuffle store, bias by border class of the output pixel
+      const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
+      const int co = ch_base - q * a.convt_co + wch * MT * 16 + g * 8;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int m = px_base + wpx * NT * 16 + nt * 16 + l15;
+        if (m >= a.M) continue;
+        int bb, pix, ho, wo;
+        fast_divmod(m, HoWo, inv_howo, bb, pix);
+        fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+        const int Y = 2 * ho + dy, X = 2 * wo + dx;
+        const int ry = Y == 0 ? 0 : (Y == 2 * a.Ho - 1 ? 2 : 1), rx = X == 0 ? 0 : (X == 2 * a.Wo - 1 ? 2 : 1);
+        const float* bp = a.bias + (ry * 3 + rx) * a.convt_co + co;
+        half_t* yp = (half_t*)a.y + (long)bb * a.y_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldy + co;
+#pragma unroll
+        for (int sg = 0; sg < MT / 2; ++sg) {
+          if (co + sg * 32 >= a.convt_co) continue;
+          const float4v b0 = *(const float4v*)(bp + sg * 32), b1 = *(const float4v*)(bp + sg * 32 + 4);
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v0 = acc[2 * sg][nt][j] + b0[j], v1 = acc[(MT >= 2 ? 2 * sg + 1 : 0)][nt][j] + b1[j];
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); }
+            o[j] = m355_to_half(v0);
+            o[4 + j] = m355_to_half(v1);
+          }
+          *(half8*)(yp + sg * 32) = o;
+        }
+      }
+      continue;
+    }
     if (MT >= 2 && fast_t) {
       const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
       const int co = ch_base - q * a.convt_co + wch * MT * 16 + g * 8;
@@ -505,12 +542,15 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   if (getenv("M355_NO_FAST_EPI")) a.dbg |= 256;
   if (getenv("M355_PERSIST") && (atoi(getenv("M355_PERSIST")) & (a.ksize == 1 ? 1 : 2))) a.dbg |= 64;
   if (a.ksize < 1 || a.ksize > 3) return -1;
-  if (a.ksize == 2 && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // only the ConvT-dgrad form
+  if (a.ksize == 2 && !a.phase && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // the ConvT-dgrad form ...
+  if (a.ksize == 2 && a.phase && (a.stride != 1 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 64)) return -1;  // ... or a phase conv
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
   if (a.M >= (1 << 24)) return -1;  // fast_divmod range
   int tile = force_tile & 0xff;
   if (force_tile < 0) tile = -1;
   if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
+  if (a.ksize == 2 && a.phase && ((tile == TILE_128x128 && a.convt_co % 128) || (tile != TILE_128x128 && tile != TILE_64x128)))
+    return -1;   // a channel tile must lie inside one phase
   switch (tile) {
     case TILE_128x128: return launch_variant<4, 4, 2, 2>(a, s);
     case TILE_64x128: return launch_variant<4, 2, 1, 4>(a, s);

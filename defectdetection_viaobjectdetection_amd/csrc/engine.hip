@@ -39,7 +39,7 @@ struct ConvLayer {
   // fused group: logical convs that were merged into this physical conv (head first-layer fusion)
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_POOL, OP_UP, OP_DECODE };
+enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_PHASE, OP_POOL, OP_UP, OP_DECODE };
 
 struct Op {
   OpKind kind;
@@ -64,6 +64,8 @@ struct Op {
 struct PhysConv {
   std::vector<int> logical;  // indices into convs_
   int cin = 0, cout = 0, k = 1, stride = 1, act = 1, transposed = 0;
+  int composed = 0;          // 1: ConvTranspose(2x2,s2) -> Conv(3x3) composed into four 2x2 phase convs (proto)
+  std::vector<float> h_wt, h_bt, h_w3, h_b3;   // host copies of the two logical convs until both are set
   int diag = 0;              // 1: block-diagonal fusion of 1x1 convs with different inputs (cin = sum of theirs)
   double macs_px = 0;        // algorithmic MACs per output pixel (diag: sum over the blocks, not cin * cout)
   int Kpad = 0, cout_pad = 0;
@@ -384,8 +386,27 @@ int build_graph(m355_engine* e) {
   {
     const int pr1 = b.tensor(H3, W3, npr), pr2 = b.tensor(H2, W2, npr), pr3 = b.tensor(H2, W2, npr);
     add_conv_op({l_p1}, Slice{t15, 0, c256}, Slice{pr1, 0, npr}, 0, 0, 0);
-    add_conv_op({l_pu}, Slice{pr1, 0, npr}, Slice{pr2, 0, npr}, 0, 0, 0, OP_CONVT);
-    add_conv_op({l_p2}, Slice{pr2, 0, npr}, Slice{pr3, 0, npr}, 0, 0, 0);
+    if (getenv("M355_NO_PROTOFUSE") || npr % 64) {   // a channel tile (64 or 128) must lie inside one phase
+      add_conv_op({l_pu}, Slice{pr1, 0, npr}, Slice{pr2, 0, npr}, 0, 0, 0, OP_CONVT);
+      add_conv_op({l_p2}, Slice{pr2, 0, npr}, Slice{pr3, 0, npr}, 0, 0, 0);
+    } else {
+      // ConvTranspose2d(2x2, s2, bias) has no activation, so upsample -> cv2's 3x3 conv is ONE linear map of the
+      // 80x80 tensor: per output phase (py, px) a 2x2 convolution with composed weights (host, fp64).  4 taps instead
+      // of 1 + 9 per output pixel, and the 160x160x128 intermediate (0.42 GB of HBM traffic at batch 32) is gone.
+      Op op{};
+      op.kind = OP_PHASE;
+      PhysConv p;
+      p.logical = {l_pu, l_p2};
+      p.cin = npr; p.cout = npr; p.k = 2; p.stride = 1; p.act = 1; p.composed = 1;
+      p.macs_px = 4.0 * (4.0 * npr) * npr;      // per LOW-resolution pixel: 4 phases x 4 taps x npr x npr
+      e->conv_phys[l_pu] = e->conv_phys[l_p2] = (int)e->phys.size();
+      e->phys.push_back(p);
+      op.conv = (int)e->phys.size() - 1;
+      op.in = Slice{pr1, 0, npr}; op.out = Slice{pr3, 0, npr};
+      // the model's nominal MACs (upstream counts ConvT + 3x3) stay in the whole-net figure
+      e->macs += (double)(2 * H3) * (2 * W3) * npr * npr + (double)(2 * H3) * (2 * W3) * npr * npr * 9;
+      e->ops.push_back(op);
+    }
     add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
   }
   {
@@ -421,14 +442,15 @@ int alloc_all(m355_engine* e) {
       total += 28 * p.cout * sizeof(float);
       continue;
     }
-    const int cout_v = p.transposed ? 4 * p.cout : p.cout;  // virtual channels of the GEMM
+    const int cout_v = (p.transposed || p.composed) ? 4 * p.cout : p.cout;  // virtual channels of the GEMM
     p.cout_pad = conv_cout_pad(cout_v);
     p.Kpad = p.transposed ? conv_kpad(p.cin, 1) : conv_kpad(p.cin, p.k);
     const size_t wb = (size_t)p.cout_pad * p.Kpad * sizeof(half_t);
     HIP_TRY(e, hipMalloc((void**)&p.w, wb));
     HIP_TRY(e, hipMemset(p.w, 0, wb));
-    HIP_TRY(e, hipMalloc((void**)&p.bias, p.cout_pad * sizeof(float)));
-    HIP_TRY(e, hipMemset(p.bias, 0, p.cout_pad * sizeof(float)));
+    const size_t nbias = p.composed ? (size_t)9 * p.cout : (size_t)p.cout_pad;   // composed: [9 border classes][cout]
+    HIP_TRY(e, hipMalloc((void**)&p.bias, nbias * sizeof(float)));
+    HIP_TRY(e, hipMemset(p.bias, 0, nbias * sizeof(float)));
     total += wb + p.cout_pad * sizeof(float);
   }
   e->ws_bytes = total;
@@ -490,6 +512,17 @@ void annotate_ops(m355_engine* e) {
                    (op.res.t >= 0 ? (double)Ho * Wo * cout_v * 2 : 0.0);
         if (op.in2.t >= 0)   // the read-through part is a quarter-size tensor
           op.bytes -= (double)ti.H * ti.W * op.in2.c * 2 * 0.75;
+        op.wbytes = (double)p.cout_pad * p.Kpad * 2;
+        break;
+      }
+      case OP_PHASE: {
+        const PhysConv& p = e->phys[op.conv];
+        const Tensor& ti = e->tensors[op.in.t];
+        op.tile = p.cout % 128 == 0 ? TILE_128x128 : TILE_64x128;
+        snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k2,phase>", tile_names[op.tile]);
+        snprintf(op.layer, sizeof(op.layer), "model.22.proto.upsample+cv2");
+        op.flops = 2.0 * ti.H * ti.W * p.macs_px;
+        op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)4 * ti.H * ti.W * p.cout * 2;
         op.wbytes = (double)p.cout_pad * p.Kpad * 2;
         break;
       }
@@ -609,6 +642,67 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
   const m355_conv_info& ci = e->convs[idx];
   PhysConv& p = e->phys[e->conv_phys[idx]];
   const int row0 = e->conv_phys_off[idx];
+  if (p.composed) {   // keep the two logical weight sets until both are here, then compose (fp64) and upload
+    const int n = p.cout;    // = cin = npr
+    if (ci.transposed) {
+      p.h_wt.assign(w, w + (size_t)n * n * 4);
+      p.h_bt.assign(bias, bias + n);
+    } else {
+      p.h_w3.assign(w, w + (size_t)n * n * 9);
+      p.h_b3.assign(bias, bias + n);
+    }
+    e->conv_loaded[idx] = true;
+    if (p.h_wt.empty() || p.h_w3.empty()) return M355_OK;
+    // Weff[q][co][(a*2+b)*n + ci] = sum over the (kh, kw) of phase q = py*2+px that fall on low-res offset (a, b):
+    //   t = py + kh - 1, low-res row offset floor(t / 2) = a - 1 + py, dy = t mod 2 (same for columns)
+    //   Weff += sum_c W3[co, c, kh, kw] * Wt[ci, c, dy, dx]
+    std::vector<half_t> rows((size_t)p.cout_pad * p.Kpad, (half_t)0.f);
+    std::vector<double> acc((size_t)n * n);
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px)
+        for (int aa = 0; aa < 2; ++aa)
+          for (int bb = 0; bb < 2; ++bb) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            for (int kh = 0; kh < 3; ++kh) {
+              const int ty = py + kh - 1, ry = (ty < 0 ? -1 : ty / 2), dy = ty & 1;
+              if (ry + 1 - py != aa) continue;
+              for (int kw = 0; kw < 3; ++kw) {
+                const int tx = px + kw - 1, rx = (tx < 0 ? -1 : tx / 2), dx = tx & 1;
+                if (rx + 1 - px != bb) continue;
+                for (int co = 0; co < n; ++co)
+                  for (int c = 0; c < n; ++c) {
+                    const double w3 = p.h_w3[(((size_t)co * n + c) * 3 + kh) * 3 + kw];
+                    if (w3 == 0.0) continue;
+                    const float* wt = &p.h_wt[(size_t)0];
+                    double* ar = &acc[(size_t)co * n];
+                    for (int cin = 0; cin < n; ++cin) ar[cin] += w3 * wt[(((size_t)cin * n + c) * 2 + dy) * 2 + dx];
+                  }
+              }
+            }
+            const int q = py * 2 + px;
+            for (int co = 0; co < n; ++co)
+              for (int cin = 0; cin < n; ++cin)
+                rows[(size_t)(q * n + co) * p.Kpad + (aa * 2 + bb) * n + cin] = (half_t)(float)acc[(size_t)co * n + cin];
+          }
+    // bias table [ry*3+rx][co]: b3 + sum over the taps of the 3x3 window that lie inside the hi-res image of W3 . bt
+    std::vector<float> btab((size_t)9 * n);
+    for (int ry = 0; ry < 3; ++ry)
+      for (int rx = 0; rx < 3; ++rx)
+        for (int co = 0; co < n; ++co) {
+          double sacc = p.h_b3[co];
+          for (int kh = 0; kh < 3; ++kh) {
+            if ((ry == 0 && kh == 0) || (ry == 2 && kh == 2)) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+              if ((rx == 0 && kw == 0) || (rx == 2 && kw == 2)) continue;
+              for (int c = 0; c < n; ++c) sacc += (double)p.h_w3[(((size_t)co * n + c) * 3 + kh) * 3 + kw] * p.h_bt[c];
+            }
+          }
+          btab[(size_t)(ry * 3 + rx) * n + co] = (float)sacc;
+        }
+    HIP_TRY(e, hipMemcpy(p.w, rows.data(), rows.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(p.bias, btab.data(), btab.size() * sizeof(float), hipMemcpyHostToDevice));
+    return M355_OK;
+  }
   if (ci.cin == 3) {  // stem: [cout][32] fp16, k = (kh*3+kw)*3+c; 1/255 is applied in the kernel's epilogue
     std::vector<half_t> sw((size_t)ci.cout * 32, (half_t)0.f);
     for (int co = 0; co < ci.cout; ++co)
@@ -669,6 +763,21 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         a.w16 = (const half_t*)p.stem_w; a.bias = p.bias;
         a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C; a.Cout = p.cout;
         rc = launch_stem(a, s);
+        break;
+      }
+      case OP_PHASE: {
+        const PhysConv& p = e->phys[op.conv];
+        const Tensor& ti = e->tensors[op.in.t];
+        const Tensor& to = e->tensors[op.out.t];
+        ConvArgs a{};
+        a.x = ti.p + op.in.off; a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C;
+        a.Hi = ti.H; a.Wi = ti.W; a.Cin = p.cin;
+        a.w = p.w; a.Kpad = p.Kpad; a.bias = p.bias; a.zero = e->zero; a.act = p.act;
+        a.ksize = 2; a.stride = 1; a.pad = 0; a.phase = 1;
+        a.Ho = ti.H; a.Wo = ti.W; a.Cout = 4 * p.cout; a.convt_co = p.cout;
+        a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
+        a.M = B * a.Ho * a.Wo;
+        rc = launch_conv_igemm(a, op.tile, s);
         break;
       }
       case OP_CONV:

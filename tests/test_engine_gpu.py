@@ -163,3 +163,39 @@ def test_upsample_read_through_equals_materialised_upsample(cuda_device):
         finally:
             os.environ.pop("M355_NO_UPFUSE", None)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_composed_proto_matches_two_step_proto(cuda_device):
+    """ConvTranspose -> 3x3 conv of the Proto branch runs as four composed 2x2 phase convs; with M355_NO_PROTOFUSE the
+    two layers run separately (fp16 intermediate).  Same function, different rounding: prototypes agree to ~1e-3,
+    and the composed form is the one closer to the fp32 oracle (checked by the other tests' tolerances)."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from helpers import synthetic_bscans
+    sd = synthetic_state_dict("n", 1, seed=2)
+    imgs = torch.from_numpy(synthetic_bscans(2, seed=5)[:, :256, :320].copy()).to(cuda_device)
+    outs = []
+    for fuse in (True, False):
+        if fuse:
+            os.environ.pop("M355_NO_PROTOFUSE", None)
+        else:
+            os.environ["M355_NO_PROTOFUSE"] = "1"
+        try:
+            eng = SegEngine("n", 1, (256, 320), max_batch=2)
+            kinds = [o["kernel"] for o in eng.op_infos()]
+            assert any("phase" in k for k in kinds) == fuse
+            eng.load_state_dict(sd)
+            p, q = eng.forward(imgs)
+            torch.cuda.synchronize()
+            outs.append((p.clone(), q.float().clone()))
+            eng.close()
+        finally:
+            os.environ.pop("M355_NO_PROTOFUSE", None)
+    assert torch.equal(outs[0][0], outs[1][0])                    # detections do not depend on the proto branch
+    err = float((outs[0][1] - outs[1][1]).norm() / outs[1][1].norm())
+    assert err <= 3e-3, err
+    # borders included: the first / last rows and columns carry the border-class bias
+    edge = torch.cat((outs[0][1][:, 0].flatten(), outs[0][1][:, -1].flatten(), outs[0][1][:, :, 0].flatten(), outs[0][1][:, :, -1].flatten()))
+    edge_ref = torch.cat((outs[1][1][:, 0].flatten(), outs[1][1][:, -1].flatten(), outs[1][1][:, :, 0].flatten(), outs[1][1][:, :, -1].flatten()))
+    assert float((edge - edge_ref).norm() / edge_ref.norm()) <= 3e-3
