@@ -50,6 +50,12 @@ struct ConvArgs {
   // (cols likewise).  Virtual channel q * convt_co + co, q = py * 2 + px, pixel-shuffle store like ConvTranspose; the
   // bias is a [9][convt_co] table indexed by the output pixel's border class (first / interior / last row x column).
   int phase;
+  // Phase conv + trailing 1x1 conv (proto.cv3) in the epilogue: y2 = act(w2 . act(phase conv) + bias2), cout2 = 32 output
+  // channels, K = convt_co = 128 (one 128 x 128 tile holds every channel of a pixel).  w2: fp16 [32][128] row-major in
+  // LOGICAL channel order; the output goes to y (ldy / y_bstride describe the 32-channel tensor).
+  const half_t* w2;
+  const float* bias2;
+  int cout2;
 };
 
 // tile ids for launch_conv_igemm(force_tile)

@@ -333,6 +333,96 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     if (a.stamps && tile == lb) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
+    if (KS == 2 && MT == 4 && NT == 4 && WCH == 2 && a.phase && a.w2) {
+      // Phase conv + proto.cv3 in one epilogue.  The 128 ch x 128 px tile Z = SiLU(phase conv) goes to LDS as fp16
+      // [pixel][128 ch] (16-byte chunk c of pixel p in slot c ^ (p & 15): conflict-free for the writes below and for the
+      // B-fragment reads), the 32 x 128 weights of the 1x1 conv likewise [row][128] with the usual row permutation;
+      // every wave then multiplies 32 channels x 32 pixels x K = 128 (16 MFMAs) and stores 8 channels per lane.
+      const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
+      __syncthreads();                                   // every wave is done with the K-loop stages
+      char* const zb = smem;                             // 128 px x 256 B
+      char* const wb2 = smem + 128 * 256;                // 32 rows x 256 B
+      for (int i = tid; i < 32 * 16; i += 256) {         // weights: LDS row R <- logical channel chl(R), chunk swizzled by R
+        const int R = i >> 4, c = i & 15;
+        const int mt2 = R >> 4, r = R & 15;
+        const int chl = (r >> 2) * 8 + mt2 * 4 + (r & 3);
+        *(float4v*)(wb2 + R * 256 + ((c ^ (R & 15)) << 4)) = *(const float4v*)(a.w2 + (long)chl * a.convt_co + c * 8);
+      }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int p = wpx * NT * 16 + nt * 16 + l15;     // pixel inside the tile
+        const int m = px_base + p;
+        const int mm = m < a.M ? m : a.M - 1;
+        int bb, pix, ho, wo;
+        fast_divmod(mm, HoWo, inv_howo, bb, pix);
+        fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+        const int Y = 2 * ho + dy, X = 2 * wo + dx;
+        const int ry = Y == 0 ? 0 : (Y == 2 * a.Ho - 1 ? 2 : 1), rx = X == 0 ? 0 : (X == 2 * a.Wo - 1 ? 2 : 1);
+        const float* bp = a.bias + (ry * 3 + rx) * a.convt_co + wch * 64 + g * 8;
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float4v b0 = *(const float4v*)(bp + sg * 32), b1 = *(const float4v*)(bp + sg * 32 + 4);
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v0 = acc[2 * sg][nt][j] + b0[j], v1 = acc[2 * sg + 1][nt][j] + b1[j];
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); }
+            o[j] = m355_to_half(v0);
+            o[4 + j] = m355_to_half(v1);
+          }
+          const int c = (wch * 64 + sg * 32 + g * 8) >> 3;   // 16-byte chunk index of these 8 channels
+          *(half8*)(zb + p * 256 + ((c ^ (p & 15)) << 4)) = o;
+        }
+      }
+      __syncthreads();
+      float4v acc2[2][2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc2[i][j] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {                   // K = 128 channels in four 32-deep slices
+        half8 a2[2], b2[2];
+        const int c = ks * 4 + g;                        // chunk of this lane's 8 k values
+#pragma unroll
+        for (int mt2 = 0; mt2 < 2; ++mt2) {
+          const int R = mt2 * 16 + l15;
+          a2[mt2] = *(const half8*)(wb2 + R * 256 + ((c ^ (R & 15)) << 4));
+        }
+#pragma unroll
+        for (int nt2 = 0; nt2 < 2; ++nt2) {
+          const int p = wave * 32 + nt2 * 16 + l15;
+          b2[nt2] = *(const half8*)(zb + p * 256 + ((c ^ (p & 15)) << 4));
+        }
+#pragma unroll
+        for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+          for (int nt2 = 0; nt2 < 2; ++nt2)
+            acc2[mt2][nt2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[mt2], b2[nt2], acc2[mt2][nt2], 0, 0, 0);
+      }
+      const float4v c0 = *(const float4v*)(a.bias2 + g * 8), c1 = *(const float4v*)(a.bias2 + g * 8 + 4);
+#pragma unroll
+      for (int nt2 = 0; nt2 < 2; ++nt2) {
+        const int m = px_base + wave * 32 + nt2 * 16 + l15;
+        if (m >= a.M) continue;
+        int bb, pix, ho, wo;
+        fast_divmod(m, HoWo, inv_howo, bb, pix);
+        fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+        const int Y = 2 * ho + dy, X = 2 * wo + dx;
+        half8 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v0 = acc2[0][nt2][j] + c0[j], v1 = acc2[1][nt2][j] + c1[j];
+          v0 = silu_f(v0);
+          v1 = silu_f(v1);
+          o[j] = m355_to_half(v0);
+          o[4 + j] = m355_to_half(v1);
+        }
+        *(half8*)((half_t*)a.y + (long)bb * a.y_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldy + g * 8) = o;
+      }
+      __syncthreads();                                   // (persistent mode: the stages are reused by the next tile)
+      continue;
+    }
     if (KS == 2 && MT >= 2 && a.phase) {   // phase conv: pixel-shuffle store, bias by border class of the output pixel
       const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
       const int co = ch_base - q * a.convt_co + wch * MT * 16 + g * 8;
@@ -551,6 +641,7 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
   if (a.ksize == 2 && a.phase && ((tile == TILE_128x128 && a.convt_co % 128) || (tile != TILE_128x128 && tile != TILE_64x128)))
     return -1;   // a channel tile must lie inside one phase
+  if (a.w2 && !(a.ksize == 2 && a.phase && tile == TILE_128x128 && a.convt_co == 128 && a.cout2 == 32 && a.bias2)) return -1;
   switch (tile) {
     case TILE_128x128: return launch_variant<4, 4, 2, 2>(a, s);
     case TILE_64x128: return launch_variant<4, 2, 1, 4>(a, s);

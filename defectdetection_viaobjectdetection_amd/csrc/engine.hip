@@ -65,6 +65,10 @@ struct PhysConv {
   std::vector<int> logical;  // indices into convs_
   int cin = 0, cout = 0, k = 1, stride = 1, act = 1, transposed = 0;
   int composed = 0;          // 1: ConvTranspose(2x2,s2) -> Conv(3x3) composed into four 2x2 phase convs (proto)
+  int l3 = -1;               // composed + this logical 1x1 conv (proto.cv3) applied in the same kernel's epilogue
+  half_t* w2 = nullptr;      // its weights, fp16 [cout2][cin] in logical order, and bias
+  float* bias2 = nullptr;
+  int cout2 = 0;
   std::vector<float> h_wt, h_bt, h_w3, h_b3;   // host copies of the two logical convs until both are set
   int diag = 0;              // 1: block-diagonal fusion of 1x1 convs with different inputs (cin = sum of theirs)
   double macs_px = 0;        // algorithmic MACs per output pixel (diag: sum over the blocks, not cin * cout)
@@ -384,30 +388,52 @@ int build_graph(m355_engine* e) {
     }
   }
   {
-    const int pr1 = b.tensor(H3, W3, npr), pr2 = b.tensor(H2, W2, npr), pr3 = b.tensor(H2, W2, npr);
+    const bool fuse2 = !getenv("M355_NO_PROTOFUSE") && npr % 64 == 0;   // a channel tile (64 or 128) must lie inside one phase
+    const bool fuse3 = fuse2 && npr == 128 && nm == 32 && !getenv("M355_NO_PROTOFUSE3");
+    const int pr1 = b.tensor(H3, W3, npr);
     add_conv_op({l_p1}, Slice{t15, 0, c256}, Slice{pr1, 0, npr}, 0, 0, 0);
-    if (getenv("M355_NO_PROTOFUSE") || npr % 64) {   // a channel tile (64 or 128) must lie inside one phase
+    if (!fuse2) {
+      const int pr2 = b.tensor(H2, W2, npr), pr3 = b.tensor(H2, W2, npr);
       add_conv_op({l_pu}, Slice{pr1, 0, npr}, Slice{pr2, 0, npr}, 0, 0, 0, OP_CONVT);
       add_conv_op({l_p2}, Slice{pr2, 0, npr}, Slice{pr3, 0, npr}, 0, 0, 0);
+      add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
     } else {
       // ConvTranspose2d(2x2, s2, bias) has no activation, so upsample -> cv2's 3x3 conv is ONE linear map of the
       // 80x80 tensor: per output phase (py, px) a 2x2 convolution with composed weights (host, fp64).  4 taps instead
       // of 1 + 9 per output pixel, and the 160x160x128 intermediate (0.42 GB of HBM traffic at batch 32) is gone.
+      // With 128 prototype channels a 128 x 128 tile holds every channel of its pixels, so proto.cv3 (1x1, 128 -> 32)
+      // runs in the same kernel's epilogue and the 160x160x128 tensor is never written at all.
       Op op{};
       op.kind = OP_PHASE;
       PhysConv p;
       p.logical = {l_pu, l_p2};
       p.cin = npr; p.cout = npr; p.k = 2; p.stride = 1; p.act = 1; p.composed = 1;
       p.macs_px = 4.0 * (4.0 * npr) * npr;      // per LOW-resolution pixel: 4 phases x 4 taps x npr x npr
+      if (fuse3) {
+        p.logical.push_back(l_p3);
+        p.l3 = l_p3;
+        p.cout2 = nm;
+        p.macs_px += 4.0 * npr * nm;
+        e->conv_phys[l_p3] = (int)e->phys.size();
+      }
       e->conv_phys[l_pu] = e->conv_phys[l_p2] = (int)e->phys.size();
       e->phys.push_back(p);
       op.conv = (int)e->phys.size() - 1;
-      op.in = Slice{pr1, 0, npr}; op.out = Slice{pr3, 0, npr};
-      // the model's nominal MACs (upstream counts ConvT + 3x3) stay in the whole-net figure
+      op.in = Slice{pr1, 0, npr};
+      // the model's nominal MACs (upstream counts ConvT + 3x3 (+ 1x1)) stay in the whole-net figure
       e->macs += (double)(2 * H3) * (2 * W3) * npr * npr + (double)(2 * H3) * (2 * W3) * npr * npr * 9;
-      e->ops.push_back(op);
+      if (fuse3) {
+        op.out = Slice{-1, 0, nm};
+        op.out_ext = 2;
+        e->macs += (double)(2 * H3) * (2 * W3) * npr * nm;
+        e->ops.push_back(op);
+      } else {
+        const int pr3 = b.tensor(H2, W2, npr);
+        op.out = Slice{pr3, 0, npr};
+        e->ops.push_back(op);
+        add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
+      }
     }
-    add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
   }
   {
     Op op{};
@@ -448,6 +474,10 @@ int alloc_all(m355_engine* e) {
     const size_t wb = (size_t)p.cout_pad * p.Kpad * sizeof(half_t);
     HIP_TRY(e, hipMalloc((void**)&p.w, wb));
     HIP_TRY(e, hipMemset(p.w, 0, wb));
+    if (p.l3 >= 0) {
+      HIP_TRY(e, hipMalloc((void**)&p.w2, (size_t)p.cout2 * p.cin * sizeof(half_t)));
+      HIP_TRY(e, hipMalloc((void**)&p.bias2, (size_t)p.cout2 * sizeof(float)));
+    }
     const size_t nbias = p.composed ? (size_t)9 * p.cout : (size_t)p.cout_pad;   // composed: [9 border classes][cout]
     HIP_TRY(e, hipMalloc((void**)&p.bias, nbias * sizeof(float)));
     HIP_TRY(e, hipMemset(p.bias, 0, nbias * sizeof(float)));
@@ -522,7 +552,11 @@ void annotate_ops(m355_engine* e) {
         snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k2,phase>", tile_names[op.tile]);
         snprintf(op.layer, sizeof(op.layer), "model.22.proto.upsample+cv2");
         op.flops = 2.0 * ti.H * ti.W * p.macs_px;
-        op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)4 * ti.H * ti.W * p.cout * 2;
+        op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)4 * ti.H * ti.W * (p.l3 >= 0 ? p.cout2 : p.cout) * 2;
+        if (p.l3 >= 0) {
+          snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<128x128,k2,phase+1x1>");
+          snprintf(op.layer, sizeof(op.layer), "model.22.proto.upsample+cv2+cv3");
+        }
         op.wbytes = (double)p.cout_pad * p.Kpad * 2;
         break;
       }
@@ -642,6 +676,14 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
   const m355_conv_info& ci = e->convs[idx];
   PhysConv& p = e->phys[e->conv_phys[idx]];
   const int row0 = e->conv_phys_off[idx];
+  if (p.composed && idx == p.l3) {   // proto.cv3 in the phase conv's epilogue: plain fp16 [cout2][cin] + bias
+    std::vector<half_t> r2((size_t)p.cout2 * p.cin);
+    for (size_t i = 0; i < r2.size(); ++i) r2[i] = (half_t)w[i];
+    HIP_TRY(e, hipMemcpy(p.w2, r2.data(), r2.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(p.bias2, bias, p.cout2 * sizeof(float), hipMemcpyHostToDevice));
+    e->conv_loaded[idx] = true;
+    return M355_OK;
+  }
   if (p.composed) {   // keep the two logical weight sets until both are here, then compose (fp64) and upload
     const int n = p.cout;    // = cin = npr
     if (ci.transposed) {
@@ -768,14 +810,19 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
       case OP_PHASE: {
         const PhysConv& p = e->phys[op.conv];
         const Tensor& ti = e->tensors[op.in.t];
-        const Tensor& to = e->tensors[op.out.t];
         ConvArgs a{};
         a.x = ti.p + op.in.off; a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C;
         a.Hi = ti.H; a.Wi = ti.W; a.Cin = p.cin;
         a.w = p.w; a.Kpad = p.Kpad; a.bias = p.bias; a.zero = e->zero; a.act = p.act;
         a.ksize = 2; a.stride = 1; a.pad = 0; a.phase = 1;
         a.Ho = ti.H; a.Wo = ti.W; a.Cout = 4 * p.cout; a.convt_co = p.cout;
-        a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
+        if (p.l3 >= 0) {
+          a.y = d_protos; a.y_bstride = (long)e->proto_h * e->proto_w * e->nm; a.ldy = e->nm;
+          a.w2 = p.w2; a.bias2 = p.bias2; a.cout2 = p.cout2;
+        } else {
+          const Tensor& to = e->tensors[op.out.t];
+          a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
+        }
         a.M = B * a.Ho * a.Wo;
         rc = launch_conv_igemm(a, op.tile, s);
         break;

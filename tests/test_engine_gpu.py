@@ -173,7 +173,16 @@ def test_composed_proto_matches_two_step_proto(cuda_device):
     from defectdetection_viaobjectdetection_amd.engine import SegEngine
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
     from helpers import synthetic_bscans
-    sd = synthetic_state_dict("n", 1, seed=2)
+    _composed_proto_case("n", cuda_device)      # 64 prototype channels: 64x128 tile, cv3 separate
+    _composed_proto_case("s", cuda_device)      # 128 channels: 128x128 tile with proto.cv3 in the epilogue
+
+
+def _composed_proto_case(scale, cuda_device):
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from helpers import synthetic_bscans
+    sd = synthetic_state_dict(scale, 1, seed=2)
     imgs = torch.from_numpy(synthetic_bscans(2, seed=5)[:, :256, :320].copy()).to(cuda_device)
     outs = []
     for fuse in (True, False):
@@ -182,9 +191,10 @@ def test_composed_proto_matches_two_step_proto(cuda_device):
         else:
             os.environ["M355_NO_PROTOFUSE"] = "1"
         try:
-            eng = SegEngine("n", 1, (256, 320), max_batch=2)
+            eng = SegEngine(scale, 1, (256, 320), max_batch=2)
             kinds = [o["kernel"] for o in eng.op_infos()]
             assert any("phase" in k for k in kinds) == fuse
+            assert any("phase+1x1" in k for k in kinds) == (fuse and scale == "s")
             eng.load_state_dict(sd)
             p, q = eng.forward(imgs)
             torch.cuda.synchronize()
