@@ -61,6 +61,13 @@ struct ConvArgs {
 // tile ids for launch_conv_igemm(force_tile)
 enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20 };
 
+// Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
+struct Knobs {
+  bool no_fast_epi, no_wide, no_persist, stem_gather;
+  int persist, halo_variant, smallm;
+};
+const Knobs& knobs();
+
 int launch_conv_igemm(const ConvArgs& a, int force_tile, hipStream_t s);
 // tile heuristic: cout = (virtual) output channels, M = output pixels of the whole batch
 int conv_pick_tile(int cout, long M);

@@ -369,12 +369,11 @@ bool conv3x3_halo_ok(const ConvArgs& a) {
 // variant: 0 = auto, 1 = 8 waves / 16x16 px, 2 = 4 waves / 8x16 px
 int launch_conv3x3_halo(const ConvArgs& a0, int variant, hipStream_t s) {
   ConvArgs a = a0;
-  if (getenv("M355_NO_FAST_EPI")) a.dbg |= 256;
+  if (knobs().no_fast_epi) a.dbg |= 256;
   if (!conv3x3_halo_ok(a)) return -1;
-  if (variant == 3 || (variant == 0 && conv3x3_wide_ok(a) && !getenv("M355_NO_WIDE"))) return launch_conv3x3_wide(a, s);
+  if (variant == 3 || (variant == 0 && conv3x3_wide_ok(a) && !knobs().no_wide)) return launch_conv3x3_wide(a, s);
   if (variant == 0) {
-    const char* ev = getenv("M355_HALO_VARIANT");
-    variant = ev ? atoi(ev) : 2;  // measured: the 4-wave variant (two blocks per CU) wins on every layer
+    variant = knobs().halo_variant;  // measured: the 4-wave variant (two blocks per CU) wins on every layer
     if (variant != 1 && variant != 2) variant = 2;
   }
   if (variant == 1) {

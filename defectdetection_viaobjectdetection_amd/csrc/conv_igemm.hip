@@ -592,7 +592,7 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   int grid_x = tiles_ch * tiles_px;
   // measured again after the fast epilogue: neutral for the 128x128 tile, 7-20 % faster for 1x1 layers on the
   // narrow channel tiles (proto.cv3 63 -> 51 us), so those run persistent
-  if ((a.dbg & 64) || (a.ksize == 1 && BCH <= 64 && !getenv("M355_NO_PERSIST"))) {
+  if ((a.dbg & 64) || (a.ksize == 1 && BCH <= 64 && !knobs().no_persist)) {
     int per_cu = (160 * 1024) / LDS;
     if (per_cu > 2) per_cu = 2;
     if (grid_x > g_num_cus * per_cu) grid_x = g_num_cus * per_cu;
@@ -613,14 +613,28 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
+const Knobs& knobs() {
+  static const Knobs k = [] {
+    Knobs v{};
+    v.no_fast_epi = getenv("M355_NO_FAST_EPI") != nullptr;
+    v.no_wide = getenv("M355_NO_WIDE") != nullptr;
+    v.no_persist = getenv("M355_NO_PERSIST") != nullptr;
+    v.stem_gather = getenv("M355_STEM_GATHER") != nullptr;
+    v.persist = getenv("M355_PERSIST") ? atoi(getenv("M355_PERSIST")) : 0;
+    v.halo_variant = getenv("M355_HALO_VARIANT") ? atoi(getenv("M355_HALO_VARIANT")) : 2;
+    v.smallm = getenv("M355_SMALLM") ? atoi(getenv("M355_SMALLM")) : 300;
+    return v;
+  }();
+  return k;
+}
+
 int conv_cout_pad(int cout) { return (cout + 127) / 128 * 128; }
 int conv_kpad(int cin, int ksize) { return (cin * ksize * ksize + BK - 1) / BK * BK; }
 
 int conv_pick_tile(int cout, long M) {
   // small pixel counts (20x20 maps at batch 32): a 128x128 grid leaves most CUs with <= 1 block; halve the
   // channel tile to double the number of blocks
-  const char* ev = getenv("M355_SMALLM");
-  const long thr = ev ? atol(ev) : 300;  // measured sweep 0/300/600/1000 on MI355X: 300 is best
+  const long thr = knobs().smallm;  // measured sweep 0/300/600/1000 on MI355X: 300 is best
   if (cout > 64 && M * ((cout + 127) / 128) / 128 < thr) return TILE_64x128;
   if (cout > 64) return TILE_128x128;
   if (cout > 32) return TILE_64x128;
@@ -629,8 +643,8 @@ int conv_pick_tile(int cout, long M) {
 
 int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   ConvArgs a = a0;
-  if (getenv("M355_NO_FAST_EPI")) a.dbg |= 256;
-  if (getenv("M355_PERSIST") && (atoi(getenv("M355_PERSIST")) & (a.ksize == 1 ? 1 : 2))) a.dbg |= 64;
+  if (knobs().no_fast_epi) a.dbg |= 256;
+  if (knobs().persist & (a.ksize == 1 ? 1 : 2)) a.dbg |= 64;
   if (a.ksize < 1 || a.ksize > 3) return -1;
   if (a.ksize == 2 && !a.phase && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // the ConvT-dgrad form ...
   if (a.ksize == 2 && a.phase && (a.stride != 1 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 64)) return -1;  // ... or a phase conv

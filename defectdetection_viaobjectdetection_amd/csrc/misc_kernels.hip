@@ -343,7 +343,7 @@ static int launch_stem_rows(const StemArgs& a, hipStream_t s) {
 }
 
 int launch_stem(const StemArgs& a, hipStream_t s) {
-  if ((a.W * 3) % 16 == 0 && a.W % 2 == 0 && a.H % 2 == 0 && 3 * (a.W * 3 + 32) <= 64 * 1024 && !getenv("M355_STEM_GATHER")) {
+  if ((a.W * 3) % 16 == 0 && a.W % 2 == 0 && a.H % 2 == 0 && 3 * (a.W * 3 + 32) <= 64 * 1024 && !knobs().stem_gather) {
     switch (a.Cout) {
       case 16: return launch_stem_rows<16>(a, s);
       case 32: return launch_stem_rows<32>(a, s);
