@@ -7,7 +7,7 @@ LABELS = {
     "conv3x3_halo_kernel<4, 4, 2, 2>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 4>": "conv3x3_halo<64ch>",
     "conv3x3_halo_kernel<4, 4, 2, 4>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 8>": "conv3x3_halo<64ch>",
     "conv_igemm_kernel<4, 4, 2, 2, 3>": "conv_igemm<128x128,k3>", "conv_igemm_kernel<4, 4, 2, 2, 1>": "conv_igemm<128x128,k1>",
-    "conv_igemm_kernel<4, 4, 2, 2, 2>": "conv_igemm<128x128,k2,phase>", "conv_igemm_kernel<4, 2, 1, 4, 2>": "conv_igemm<64x128,k2,phase>",
+    "conv_igemm_kernel<4, 4, 2, 2, 2>": "conv_igemm<128x128,k2,phase+1x1>", "conv_igemm_kernel<4, 2, 1, 4, 2>": "conv_igemm<64x128,k2,phase>",
     "conv_igemm_kernel<4, 2, 1, 4, 3>": "conv_igemm<64x128,k3>", "conv_igemm_kernel<4, 2, 1, 4, 1>": "conv_igemm<64x128,k1>",
     "conv_igemm_kernel<2, 4, 1, 4, 3>": "conv_igemm<32x256,k3>", "conv_igemm_kernel<2, 4, 1, 4, 1>": "conv_igemm<32x256,k1>",
     "conv3x3_wide_kernel": "conv3x3_wide<128ch,16x16px>", "conv3x3_c32_kernel": "conv3x3_c32<32ch,16x16px>",
