@@ -59,11 +59,11 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_LEAN = 21, TILE_LEAN128x8 = 22, TILE_LEAN64x16 = 23, TILE_LEAN128x16 = 24 };
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {
-  bool no_fast_epi, no_wide, no_persist, stem_gather;
+  bool no_fast_epi, no_wide, no_persist, stem_gather, lean;
   int persist, halo_variant, smallm;
 };
 const Knobs& knobs();
@@ -81,6 +81,8 @@ int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // vari
 // 128 ch x 16x16 px, K depth 32 per step (conv3x3_wide.hip)
 bool conv3x3_wide_ok(const ConvArgs& a);
 int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s);
+// the same pipeline as a template over (channel block, tile height): conv3x3_lean.hip; which 0 = by shape
+int launch_conv3x3_lean(const ConvArgs& a, int which, hipStream_t s);
 // Cin = Cout = 32, weights-stationary persistent halo kernel (conv3x3_c32.hip)
 bool conv3x3_c32_ok(const ConvArgs& a);
 int launch_conv3x3_c32(const ConvArgs& a, hipStream_t s);

@@ -618,6 +618,7 @@ const Knobs& knobs() {
     Knobs v{};
     v.no_fast_epi = getenv("M355_NO_FAST_EPI") != nullptr;
     v.no_wide = getenv("M355_NO_WIDE") != nullptr;
+    v.lean = getenv("M355_LEAN") != nullptr;
     v.no_persist = getenv("M355_NO_PERSIST") != nullptr;
     v.stem_gather = getenv("M355_STEM_GATHER") != nullptr;
     v.persist = getenv("M355_PERSIST") ? atoi(getenv("M355_PERSIST")) : 0;
@@ -664,6 +665,8 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
     // 8 waves x (32 ch x 32 px), four waves per SIMD: measured equal to the 4-wave tiles on every layer class
     // (tools/tile_sweep.py: the 1x1 layers run at 4.6 TB/s in isolation whatever the tile); kept for experiments
     case TILE_64x128W8: return launch_variant<2, 2, 2, 4>(a, s);
+    // 8 waves x (64 ch x 64 px), 128x256 and 256x128 tiles (one block per CU, 0.19 instead of 0.25 KiB of LDS intake per
+    // MFMA): 5-20 % slower than the 4-wave tiles on every 3x3 / stride-2 / 1x1 layer class of this network; removed
     default: return -1;
   }
 }
