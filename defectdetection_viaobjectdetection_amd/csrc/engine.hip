@@ -57,6 +57,10 @@ struct Op {
   double bytes = 0;       // algorithmic activation bytes per image (in + out + residual)
   double wbytes = 0;      // weight bytes (read once per launch)
   int tile = -1;
+  // stream lanes (plan_lanes): lane 0 is the caller's stream, lanes >= 1 are engine-owned side streams
+  int lane = 0;
+  std::vector<int> wait_ops;   // ops on OTHER lanes whose completion event this op's stream waits for before the launch
+  bool record = false;         // an op on another lane (or the end-of-forward join) waits for this op
 };
 
 // A physical conv = what one kernel launch computes.  Usually one logical conv; the three first-layer
@@ -100,7 +104,13 @@ struct m355_engine {
   size_t ws_bytes = 0;
   double macs = 0;           // conv MACs per image
   int feat_in = -1;
-  // profiling: HIP events around every op launch, recorded on the caller's stream
+  // stream lanes: independent branches of the graph (Proto + the stride-8 head level vs the rest of the neck and the
+  // other head levels) are launched on two streams so that the tails / partial waves of one fill the other's gaps
+  int nlanes = 1;
+  std::vector<hipStream_t> side;      // lanes 1 .. nlanes-1
+  std::vector<hipEvent_t> op_done;    // one per op with record == true (else nullptr)
+  std::vector<int> lane_last;         // last op of every lane (joined into the caller's stream at the end of a forward)
+  // profiling: HIP events around every op launch, recorded on the caller's stream (single lane while profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;   // 2 events per op per recorded forward
   size_t ev_used = 0;
@@ -365,7 +375,12 @@ int build_graph(m355_engine* e) {
     e->ops.push_back(op);
   };
   const int HW[3][2] = {{H3, W3}, {H4, W4}, {H5, W5}};
+  // stream lane of Proto and of the three head levels (plan_lanes): measured best on MI355X at batch 32
+  int lane_plan[4] = {1, 2, 2, 0};
+  if (const char* lp = getenv("M355_LANE_PLAN"))
+    for (int i = 0; i < 4 && lp[i] >= '0' && lp[i] <= '3'; ++i) lane_plan[i] = lp[i] - '0';
   for (int l = 0; l < 3; ++l) {
+    const size_t lvl_first = e->ops.size();
     const int hcat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
     const Slice f{feats[l], 0, fch[l]};
     add_conv_op({l_cv2[l][0], l_cv3[l][0], l_cv4[l][0]}, f, Slice{hcat, 0, hc2 + hc3 + hc4}, 0, 0, 0);
@@ -386,7 +401,9 @@ int build_graph(m355_engine* e) {
       b.add_macs(op, e->phys[op.conv]);
       e->ops.push_back(op);
     }
+    for (size_t i = lvl_first; i < e->ops.size(); ++i) e->ops[i].lane = lane_plan[1 + l];
   }
+  const size_t proto_first = e->ops.size();
   {
     const bool fuse2 = !getenv("M355_NO_PROTOFUSE") && npr % 64 == 0;   // a channel tile (64 or 128) must lie inside one phase
     const bool fuse3 = fuse2 && npr == 128 && nm == 32 && !getenv("M355_NO_PROTOFUSE3");
@@ -435,12 +452,89 @@ int build_graph(m355_engine* e) {
       }
     }
   }
+  for (size_t i = proto_first; i < e->ops.size(); ++i) e->ops[i].lane = lane_plan[0];
   {
     Op op{};
     op.kind = OP_DECODE;
     e->ops.push_back(op);
   }
   e->proto_h = H2; e->proto_w = W2;
+  return 0;
+}
+
+// Producers of op i in the current op order: earlier ops that write a tensor it reads; the decode reads the raw head map.
+std::vector<int> op_producers(const m355_engine* e, int i) {
+  const Op& op = e->ops[i];
+  std::vector<int> r;
+  for (int j = 0; j < i; ++j) {
+    const Op& q = e->ops[j];
+    if (op.kind == OP_DECODE) {
+      if (q.out_ext == 1) r.push_back(j);
+      continue;
+    }
+    if (q.out_ext != 0 || q.out.t < 0) continue;
+    if (q.out.t == op.in.t || (op.in2.t >= 0 && q.out.t == op.in2.t) || (op.res.t >= 0 && q.out.t == op.res.t)) r.push_back(j);
+  }
+  return r;
+}
+
+// Stream lanes.  The builder tags the ops of Proto and of the stride-8 head level with lane 1; everything else is
+// lane 0 (the caller's stream).  (1) Reorder: a lane-1 op moves to right after the last lane-0 op it depends on, so the
+// host enqueues it as early as the data allows (lane order is kept, so the result is still a topological order).
+// (2) Cross-lane dependencies become event waits; the last op of every side lane is joined into the caller's stream.
+int plan_lanes(m355_engine* e) {
+  if (getenv("M355_NO_LANES")) {
+    for (Op& op : e->ops) op.lane = 0;
+    return 0;
+  }
+  const int n = (int)e->ops.size();
+  int nl = 1;
+  for (const Op& op : e->ops) nl = std::max(nl, op.lane + 1);
+  if (nl == 1) return 0;
+  std::vector<int> ready(n, -1);          // side-lane op: index (old order) of its last lane-0 producer
+  for (int i = 0; i < n; ++i) {
+    if (e->ops[i].lane == 0) continue;
+    for (int p : op_producers(e, i))
+      if (e->ops[p].lane == 0) ready[i] = std::max(ready[i], p);
+  }
+  std::vector<Op> order;
+  std::vector<int> pending;               // side-lane ops in their original order
+  for (int i = 0; i < n; ++i)
+    if (e->ops[i].lane != 0) pending.push_back(i);
+  size_t pi = 0;
+  int run_ready = -1;                     // a side op also waits for the side ops before it: running maximum
+  for (int i = 0; i < n; ++i) {
+    if (e->ops[i].lane != 0) continue;
+    order.push_back(e->ops[i]);
+    while (pi < pending.size()) {
+      run_ready = std::max(run_ready, ready[pending[pi]]);
+      if (run_ready > i) break;
+      order.push_back(e->ops[pending[pi++]]);
+    }
+  }
+  while (pi < pending.size()) order.push_back(e->ops[pending[pi++]]);
+  e->ops.swap(order);
+  e->lane_last.assign(nl, -1);
+  for (int i = 0; i < n; ++i) {
+    Op& op = e->ops[i];
+    e->lane_last[op.lane] = i;
+    std::vector<int> latest(nl, -1);      // stream order covers the earlier ops of a lane: wait for the latest only
+    for (int p : op_producers(e, i))
+      if (e->ops[p].lane != op.lane) latest[e->ops[p].lane] = std::max(latest[e->ops[p].lane], p);
+    for (int l = 0; l < nl; ++l)
+      if (latest[l] >= 0) {
+        op.wait_ops.push_back(latest[l]);
+        e->ops[latest[l]].record = true;
+      }
+  }
+  for (int l = 1; l < nl; ++l)
+    if (e->lane_last[l] >= 0) e->ops[e->lane_last[l]].record = true;
+  e->op_done.assign(n, nullptr);
+  for (int i = 0; i < n; ++i)
+    if (e->ops[i].record) HIP_TRY(e, hipEventCreateWithFlags(&e->op_done[i], hipEventDisableTiming));
+  e->side.assign(nl - 1, nullptr);
+  for (int l = 1; l < nl; ++l) HIP_TRY(e, hipStreamCreateWithFlags(&e->side[l - 1], hipStreamNonBlocking));
+  e->nlanes = nl;
   return 0;
 }
 
@@ -627,6 +721,7 @@ int m355_create(const m355_model_desc* desc, m355_engine** out) {
   m355_engine* e = new m355_engine();
   e->desc = *desc;
   int rc = build_graph(e);
+  if (rc == 0) rc = plan_lanes(e);
   if (rc == 0) rc = alloc_all(e);
   if (rc == 0) annotate_ops(e);
   if (rc != 0) {
@@ -651,6 +746,10 @@ void m355_destroy(m355_engine* e) {
   if (e->zero) (void)hipFree(e->zero);
   if (e->nms_ws) (void)hipFree(e->nms_ws);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
+  for (hipEvent_t ev : e->op_done)
+    if (ev) (void)hipEventDestroy(ev);
+  for (hipStream_t st : e->side)
+    if (st) (void)hipStreamDestroy(st);
   delete e;
 }
 
@@ -783,11 +882,15 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
   if (B < 1 || B > e->desc.max_batch) return e->fail(M355_ERR_STATE, "batch exceeds max_batch");
   for (size_t i = 0; i < e->conv_loaded.size(); ++i)
     if (!e->conv_loaded[i]) return e->fail(M355_ERR_STATE, std::string("weights not set for ") + e->convs[i].name);
-  hipStream_t s = (hipStream_t)stream;
+  hipStream_t s_main = (hipStream_t)stream;
   const int rw = 64 + e->nc + e->nm;
+  const bool lanes = e->nlanes > 1 && !e->profiling;   // per-op event timing needs one stream
   for (size_t oi = 0; oi < e->ops.size(); ++oi) {
     const Op& op = e->ops[oi];
     int rc = 0;
+    hipStream_t s = (lanes && op.lane > 0) ? e->side[op.lane - 1] : s_main;
+    if (lanes)
+      for (int p : op.wait_ops) HIP_TRY(e, hipStreamWaitEvent(s, e->op_done[p], 0));
     if (e->profiling) {
       if (e->ev_used + 2 > e->ev_pool.size()) {
         for (int i = 0; i < 2; ++i) {
@@ -895,7 +998,11 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
     }
     if (rc != 0) return e->fail(M355_ERR_HIP, "kernel launch failed (op kind " + std::to_string((int)op.kind) +
                                                   ", code " + std::to_string(rc) + ")");
+    if (lanes && op.record) HIP_TRY(e, hipEventRecord(e->op_done[oi], s));
   }
+  if (lanes)   // join: everything this forward launched is ordered before whatever the caller enqueues next
+    for (int l = 1; l < e->nlanes; ++l)
+      if (e->lane_last[l] >= 0) HIP_TRY(e, hipStreamWaitEvent(s_main, e->op_done[e->lane_last[l]], 0));
   return M355_OK;
 }
 
