@@ -35,6 +35,12 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not record per-op HIP events")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of overlapping it with the next batch")
+    ap.add_argument("--engines", type=int, default=2,
+                    help="engine instances (own activations and streams) that take the batches in turn: two batches "
+                         "are in flight, the small-map tail of one forward runs beside the large-map start of the next")
+    ap.add_argument("--serial", action="store_true",
+                    help="one engine, one stream lane inside it (M355_NO_LANES): every kernel runs alone, so rocprofv3's "
+                         "per-kernel averages and the live event samples describe the same launches")
     ap.add_argument("--profile-every", type=int, default=10,
                     help="record per-op HIP events on every n-th timed step (an event pair per launch costs "
                          "~8 us of serialisation, ~0.6 ms per fully instrumented step)")
@@ -61,44 +67,62 @@ def main():
 
     B = args.batch
     sd = synthetic_state_dict(args.scale, 1, seed=0)
-    eng = SegEngine(args.scale, 1, (640, 640), max_batch=B, device=local_rank)
-    eng.load_state_dict(sd)
+    if args.serial:
+        os.environ["M355_NO_LANES"] = "1"
+        args.engines = 1
+    n_eng = max(1, args.engines)
+    engs = []
+    for _ in range(n_eng):
+        e_ = SegEngine(args.scale, 1, (640, 640), max_batch=B, device=local_rank)
+        e_.load_state_dict(sd)
+        engs.append(e_)
+    eng = engs[0]
     imgs = torch.from_numpy(synthetic_bscans(B, seed=1000 + rank)).cuda()
     conf, iou, max_det = 0.25, 0.7, 300
 
     # persistent output buffers (caller-owned), allocated once outside the timed region
     import ctypes as C
     from defectdetection_viaobjectdetection_amd._capi import check, lib
-    # Two sets of caller-owned buffers: the post-processing of batch i (NMS: one block per image, then the mask
-    # kernel) runs on a second HIP stream while the forward pass of batch i+1 fills the other set.  Every batch is
-    # fully processed inside the timed region; --no-overlap puts both on one stream.
+    # Pipeline: batch i goes to engine i % n_eng, which owns a forward stream, a post-processing stream and two sets of
+    # caller-owned output buffers.  The post-processing of a batch (NMS: one block per image, then the mask kernel)
+    # runs beside later forwards; with two engines two forwards are in flight as well.  Every batch is fully processed
+    # inside the timed region; --no-overlap puts post-processing on the forward stream, --serial removes all overlap.
     nbuf = 1 if args.no_overlap else 2
-    preds = [torch.empty((B, eng.num_anchors, eng.pred_width), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-    protos = [torch.empty((B, eng.proto_hw[0], eng.proto_hw[1], 32), dtype=torch.float16, device="cuda") for _ in range(nbuf)]
-    dets = [torch.empty((B, max_det, 38), dtype=torch.float32, device="cuda") for _ in range(nbuf)]
-    counts_b = [torch.zeros((B,), dtype=torch.int32, device="cuda") for _ in range(nbuf)]
-    masks = [torch.empty((B, max_det, 640, 640), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-    s_fwd = torch.cuda.current_stream()
-    s_post = s_fwd if args.no_overlap else torch.cuda.Stream()
-    ev_fwd = [torch.cuda.Event() for _ in range(nbuf)]
-    ev_post = [torch.cuda.Event() for _ in range(nbuf)]
-    h_fwd, h_post = C.c_void_p(s_fwd.cuda_stream), C.c_void_p(s_post.cuda_stream)
+    mk = lambda shape, dt: [[torch.empty(shape, dtype=dt, device="cuda") for _ in range(nbuf)] for _ in range(n_eng)]  # noqa: E731
+    preds = mk((B, eng.num_anchors, eng.pred_width), torch.float32)
+    protos = mk((B, eng.proto_hw[0], eng.proto_hw[1], 32), torch.float16)
+    dets = mk((B, max_det, 38), torch.float32)
+    counts_b = [[torch.zeros((B,), dtype=torch.int32, device="cuda") for _ in range(nbuf)] for _ in range(n_eng)]
+    masks = mk((B, max_det, 640, 640), torch.uint8)
+    s_fwd = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_eng - 1)]
+    s_post = [s_fwd[e] if args.no_overlap else torch.cuda.Stream() for e in range(n_eng)]
+    ev_fwd = [[torch.cuda.Event() for _ in range(nbuf)] for _ in range(n_eng)]
+    ev_post = [[torch.cuda.Event() for _ in range(nbuf)] for _ in range(n_eng)]
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     step_no = [0]
+    last_fwd = [None]     # event after the most recent forward (any engine)
 
-    def step():
-        k = step_no[0] % nbuf
+    def step(alone=False):
+        """alone: this forward does not overlap any other forward (event-sampled steps: per-kernel times are clean)."""
+        i = step_no[0]
         step_no[0] += 1
+        e, k = i % n_eng, (i // n_eng) % nbuf
+        sf, sp = s_fwd[e], s_post[e]
         if nbuf == 2:
-            s_fwd.wait_event(ev_post[k])          # the post-processing that last read buffer set k (batch i-2) is done
-        check(lib.m355_forward(eng._h, P(imgs), B, P(preds[k]), P(protos[k]), h_fwd), eng._h)
+            sf.wait_event(ev_post[e][k])          # the post-processing that last read this buffer set is done
+        if (alone or step.prev_alone) and last_fwd[0] is not None:
+            sf.wait_event(last_fwd[0])            # serialise against the previous forward (other engine's stream)
+        check(lib.m355_forward(engs[e]._h, P(imgs), B, P(preds[e][k]), P(protos[e][k]), C.c_void_p(sf.cuda_stream)), engs[e]._h)
+        ev_fwd[e][k].record(sf)
+        last_fwd[0] = ev_fwd[e][k]
+        step.prev_alone = alone
+        if sp is not sf:
+            sp.wait_event(ev_fwd[e][k])
+        check(lib.m355_postprocess(engs[e]._h, P(preds[e][k]), P(protos[e][k]), B, conf, iou, max_det, P(dets[e][k]),
+                                   P(counts_b[e][k]), P(masks[e][k]), C.c_void_p(sp.cuda_stream)), engs[e]._h)
         if nbuf == 2:
-            ev_fwd[k].record(s_fwd)
-            s_post.wait_event(ev_fwd[k])
-        check(lib.m355_postprocess(eng._h, P(preds[k]), P(protos[k]), B, conf, iou, max_det, P(dets[k]), P(counts_b[k]),
-                                   P(masks[k]), h_post), eng._h)
-        if nbuf == 2:
-            ev_post[k].record(s_post)
+            ev_post[e][k].record(sp)
+    step.prev_alone = False
 
     def barrier():
         if dist is not None:
@@ -110,17 +134,19 @@ def main():
     barrier()
     profile = not args.no_profile
     if profile:
-        eng.collect_op_times()  # drain + reset
+        for e_ in engs:
+            e_.collect_op_times()  # drain + reset
     sampled = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
         on = profile and (i % args.profile_every == args.profile_every // 2 or args.steps < args.profile_every)
+        cur = engs[step_no[0] % n_eng]
         if on:
-            eng.set_profiling(True)
+            cur.set_profiling(True)
             sampled += 1
-        step()
+        step(alone=on)
         if on:
-            eng.set_profiling(False)
+            cur.set_profiling(False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -130,7 +156,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms_sum, cnt = eng.collect_op_times() if profile else ([], [])
+    ms_sum, cnt = [], []
+    if profile:
+        for e_ in engs:   # every engine has the same op list: add the samples up
+            m_, c_ = e_.collect_op_times()
+            ms_sum = list(m_) if not ms_sum else [a + b for a, b in zip(ms_sum, m_)]
+            cnt = list(c_) if not cnt else [a + b for a, b in zip(cnt, c_)]
 
     total_images = world * B * args.steps
     value = total_images / elapsed
@@ -143,8 +174,11 @@ def main():
                                f"B-scans per GPU per step, nc=1, seeded synthetic weights",
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
                    "conf": conf, "iou": iou, "max_det": max_det,
-                   "mean_detections_per_image": round(float(counts_b[0].float().mean()), 2),
-                   "pipelining": "none" if args.no_overlap else "post-processing of batch i overlaps forward of batch i+1 (2 HIP streams)"},
+                   "mean_detections_per_image": round(float(counts_b[0][0].float().mean()), 2),
+                   "engines_in_flight": n_eng, "stream_lanes_per_engine": 1 if os.environ.get("M355_NO_LANES") else 3,
+                   "pipelining": ("none" if args.no_overlap and n_eng == 1 else
+                                  f"{n_eng} batch(es) in flight on {n_eng} engine instance(s); post-processing of a batch "
+                                  f"overlaps later forwards (own HIP stream); event-sampled steps run their forward alone")},
     }
     if rank == 0:
         gflop_img = eng.flops_per_image / 1e9

@@ -209,3 +209,59 @@ def _composed_proto_case(scale, cuda_device):
     edge = torch.cat((outs[0][1][:, 0].flatten(), outs[0][1][:, -1].flatten(), outs[0][1][:, :, 0].flatten(), outs[0][1][:, :, -1].flatten()))
     edge_ref = torch.cat((outs[1][1][:, 0].flatten(), outs[1][1][:, -1].flatten(), outs[1][1][:, :, 0].flatten(), outs[1][1][:, :, -1].flatten()))
     assert float((edge - edge_ref).norm() / edge_ref.norm()) <= 3e-3
+
+
+def test_stream_lanes_equal_single_stream(cuda_device):
+    """Proto and the head levels run on engine-owned side streams (plan_lanes in engine.hip); M355_NO_LANES puts every
+    op on the caller's stream.  Same kernels, same inputs: bit-identical outputs, also when forwards follow each other
+    without a host synchronisation (the join at the end of a forward orders the next one) and when two engines run on
+    two caller streams at once (bench.py's two batches in flight)."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    batches = [torch.from_numpy(synthetic_bscans(3, seed=20 + i)[:, :256, :320].copy()).to(cuda_device) for i in range(3)]
+
+    def make(no_lanes):
+        if no_lanes:
+            os.environ["M355_NO_LANES"] = "1"
+        try:
+            eng = SegEngine("s", 1, (256, 320), max_batch=3)
+        finally:
+            os.environ.pop("M355_NO_LANES", None)
+        eng.load_state_dict(sd)
+        return eng
+
+    ref_eng = make(True)
+    ref = []
+    for x in batches:
+        p, q = ref_eng.forward(x)
+        torch.cuda.synchronize()
+        ref.append((p.clone(), q.clone()))
+    ref_eng.close()
+
+    a, b = make(False), make(False)
+    # back-to-back forwards on one stream, results copied out by stream-ordered clones
+    got = []
+    for x in batches * 2:
+        p, q = a.forward(x)
+        got.append((p.clone(), q.clone()))
+    torch.cuda.synchronize()
+    for i, (p, q) in enumerate(got):
+        assert torch.equal(p, ref[i % 3][0]) and torch.equal(q, ref[i % 3][1]), i
+    # two engines, two streams, concurrently
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for rep in range(3):
+        with torch.cuda.stream(s1):
+            p1, q1 = a.forward(batches[rep])
+            outs.append((rep, p1.clone(), q1.clone()))
+        with torch.cuda.stream(s2):
+            p2, q2 = b.forward(batches[(rep + 1) % 3])
+            outs.append(((rep + 1) % 3, p2.clone(), q2.clone()))
+    torch.cuda.synchronize()
+    for i, p, q in outs:
+        assert torch.equal(p, ref[i][0]) and torch.equal(q, ref[i][1]), i
+    a.close()
+    b.close()

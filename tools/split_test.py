@@ -36,3 +36,23 @@ def two_seq():
     check(lib.m355_forward(eb._h, P(xb), 16, P(pb), P(qb), C.c_void_p(s1.cuda_stream)), eb._h)
 t = timeit(two_seq)
 print(f"two engines b16 on one stream: {t:.3f} ms / 32 images")
+# two FULL-batch engines alternating on two streams, half a forward out of phase
+del ea, eb
+eA, eB = e32, SegEngine("s", 1, (640, 640), max_batch=32)
+eB.load_state_dict(sd)
+pB, qB = bufs(eB, 32)
+def fa(): check(lib.m355_forward(eA._h, P(x), 32, P(p32), P(q32), C.c_void_p(s1.cuda_stream)), eA._h)
+def fb(): check(lib.m355_forward(eB._h, P(x), 32, P(pB), P(qB), C.c_void_p(s2.cuda_stream)), eB._h)
+for off_ms in (0.0, 0.6, 1.1, 1.6):
+    torch.cuda.synchronize()
+    fa(); torch.cuda.synchronize(); fb(); torch.cuda.synchronize()
+    n = 30
+    t0 = time.perf_counter()
+    fa()
+    time.sleep(off_ms * 1e-3)
+    fb()
+    for _ in range(n - 1):
+        fa(); fb()
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / (2 * n) * 1e3
+    print(f"two b32 engines, two streams, B enqueued {off_ms} ms after A: {t:.3f} ms / 32 images")
