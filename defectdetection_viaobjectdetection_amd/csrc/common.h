@@ -81,6 +81,11 @@ int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // vari
 // 128 ch x 16x16 px, K depth 32 per step (conv3x3_wide.hip)
 bool conv3x3_wide_ok(const ConvArgs& a);
 int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s);
+// D-FINE decoder ops (dfine_kernels.hip)
+int launch_msda(const float* value, const float* loc, const float* attn, float* out, int B, int S, int H, int D, int Q, int P,
+                int L, const int* shapes_hw, const int* points_per_level, int discrete, hipStream_t s);
+int launch_dfine_decode(const float* dist, const float* project, const float* ref, float* boxes, long n, int nbins1,
+                        float reg_scale, int clamp01, hipStream_t s);
 // the same pipeline as a template over (channel block, tile height): conv3x3_lean.hip; which 0 = by shape
 int launch_conv3x3_lean(const ConvArgs& a, int which, hipStream_t s);
 // Cin = Cout = 32, weights-stationary persistent halo kernel (conv3x3_c32.hip)

@@ -1392,6 +1392,23 @@ int m355_augment(const void* d_cache, const m355_aug_params* d_params, void* d_o
   const int rc = m355::launch_augment((const uint8_t*)d_cache, d_params, (uint8_t*)d_out, B, H, W, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "augment launch failed: " + std::to_string(rc));
 }
+int m355_msda_forward(const float* d_value, int32_t B, int32_t S, int32_t heads, int32_t head_dim, const int32_t* shapes_hw,
+                      int32_t num_levels, const float* d_loc, const float* d_attn, const int32_t* points_per_level,
+                      int32_t Q, int32_t P, int32_t discrete, float* d_out, void* stream) {
+  if (!d_value || !d_loc || !d_attn || !d_out || !shapes_hw || !points_per_level) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = m355::launch_msda(d_value, d_loc, d_attn, d_out, B, S, heads, head_dim, Q, P, num_levels, shapes_hw,
+                                   points_per_level, discrete, (hipStream_t)stream);
+  if (rc == -1)
+    return set_err(M355_ERR_INVALID, "msda: head_dim must be 32, 1..8 levels tiling S, 1..32 points tiling P");
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "msda launch failed: " + std::to_string(rc));
+}
+int m355_dfine_decode(const float* d_dist, const float* d_project, const float* d_ref, float* d_boxes, int64_t n,
+                      int32_t num_bins_plus1, float reg_scale, int32_t clamp01, void* stream) {
+  const int rc = m355::launch_dfine_decode(d_dist, d_project, d_ref, d_boxes, (long)n, num_bins_plus1, reg_scale, clamp01,
+                                           (hipStream_t)stream);
+  if (rc == -1) return set_err(M355_ERR_INVALID, "dfine_decode: null pointer, n < 0, fewer than 2 bins or reg_scale == 0");
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "dfine_decode launch failed: " + std::to_string(rc));
+}
 int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

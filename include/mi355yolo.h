@@ -236,6 +236,26 @@ typedef struct {
 int m355_augment(const void* d_cache, const m355_aug_params* d_params, void* d_out, int32_t B, int32_t H, int32_t W,
                  void* stream);
 
+/* ---- D-FINE decoder hot ops (/root/reference/D-Fine/temporal_dfine.py:160-181) ---------------
+ * The reference reaches these through transformers' modeling_d_fine.py; each entry point names what it replaces.
+ *
+ * m355_msda_forward = multi_scale_deformable_attention_v2 (modeling_d_fine.py:150-221), called by every decoder
+ * layer's cross-attention under `self.dfine.model(pixel_values=...)` (temporal_dfine.py:162).
+ *   value  (B, S, heads, head_dim) fp32, S = sum of h*w over the levels, head_dim must be 32
+ *   shapes_hw: HOST array [num_levels][2] = (height, width); points_per_level: HOST array, sums to P (<= 32)
+ *   loc    (B, Q, heads, P, 2) fp32 (x, y); attn (B, Q, heads, P) fp32 (already soft-maxed by the caller)
+ *   discrete 0: method "default" (bilinear grid_sample on 2*loc-1, zeros padding, align_corners=False)
+ *            1: method "discrete" (nearest pixel of loc * (w, h) + 0.5, clamped)
+ *   out    (B, Q, heads * head_dim) fp32 */
+int m355_msda_forward(const float* d_value, int32_t B, int32_t S, int32_t heads, int32_t head_dim, const int32_t* shapes_hw,
+                      int32_t num_levels, const float* d_loc, const float* d_attn, const int32_t* points_per_level,
+                      int32_t Q, int32_t P, int32_t discrete, float* d_out, void* stream);
+/* m355_dfine_decode = DFineIntegral.forward (modeling_d_fine.py:756-778) + distance2bbox (:1115-1137) [+ .clamp(0, 1)],
+ * temporal_dfine.py:180-181.  dist (n, 4 * num_bins_plus1) fp32 logits; project (num_bins_plus1) fp32 = W(n) from
+ * weighting_function (:1091-1112, host side: dfine.py); ref (n, 4) fp32 (cx, cy, w, h); boxes (n, 4) fp32 (cx, cy, w, h). */
+int m355_dfine_decode(const float* d_dist, const float* d_project, const float* d_ref, float* d_boxes, int64_t n,
+                      int32_t num_bins_plus1, float reg_scale, int32_t clamp01, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

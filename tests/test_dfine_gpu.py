@@ -1,0 +1,130 @@
+"""D-FINE decoder hot ops: HIP kernels through the C-ABI against the transformers-generated golden
+vectors and the numpy oracle.  Tolerance: fp32 arithmetic on both sides, different summation order and exp
+implementation: |err| <= 1e-5 * max(1, |ref|max)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+G = np.load(os.path.join(ROOT, "tests", "golden", "dfine_golden.npz"))
+SHAPES = [tuple(int(v) for v in hw) for hw in G["shapes"]]
+TOL = 1e-5
+
+
+def _t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("method", ["default", "discrete"])
+def test_msda_golden(tag, method, cuda_device):
+    from defectdetection_viaobjectdetection_amd import dfine
+    y = dfine.multi_scale_deformable_attention_v2(_t(G["value"], cuda_device), SHAPES, _t(G[f"loc_{tag}"], cuda_device),
+                                                  _t(G[f"attn_{tag}"], cuda_device), [int(n) for n in G[f"pts_{tag}"]], method)
+    ref = G[f"msda_{tag}_{method}"]
+    err = np.abs(y.cpu().numpy() - ref).max()
+    assert err <= TOL * max(1.0, np.abs(ref).max()), err
+
+
+def test_msda_vs_oracle_ragged_and_edges(cuda_device):
+    """One level of one pixel, a 1 x 7 strip, Q = 1, a 6-d location tensor as the attention module passes it, every
+    point outside the map (all-zero output), points exactly on pixel centres."""
+    import dfine_oracle as orc
+    from defectdetection_viaobjectdetection_amd import dfine
+    rng = np.random.default_rng(3)
+    shapes = [(1, 1), (1, 7), (6, 3)]
+    S = sum(h * w for h, w in shapes)
+    B, Q, H, D, pts = 3, 1, 2, 32, [1, 2, 5]
+    value = rng.standard_normal((B, S, H, D)).astype(np.float32)
+    loc = (rng.random((B, Q, H, 8, 2)) * 1.6 - 0.3).astype(np.float32)
+    loc[0, 0, 0, 3] = (0.5 / 3, 0.5 / 6)          # centre of pixel (0, 0) of the 6 x 3 level: weight 1 on one corner
+    loc[1] = 7.0                                   # far outside: zero padding everywhere
+    attn = rng.random((B, Q, H, 8)).astype(np.float32)
+    for method in ("default", "discrete"):
+        ref = orc.multi_scale_deformable_attention_v2(value, shapes, loc, attn, pts, method)
+        y = dfine.multi_scale_deformable_attention_v2(_t(value, cuda_device), shapes, _t(loc[:, :, :, None], cuda_device),
+                                                      _t(attn, cuda_device), pts, method).cpu().numpy()
+        assert np.abs(y - ref).max() <= TOL * max(1.0, np.abs(ref).max()), method
+        if method == "default":
+            assert np.all(y[1] == 0)
+
+
+def test_msda_many_points_scalar_form(cuda_device):
+    """More than 16 points per head take the scalar kernel (one 32-lane group per (b, q, h)); up to 16 the wave kernel."""
+    import dfine_oracle as orc
+    from defectdetection_viaobjectdetection_amd import dfine
+    rng = np.random.default_rng(9)
+    shapes = [(9, 11), (4, 6), (2, 3)]
+    S = sum(h * w for h, w in shapes)
+    B, Q, H, D = 2, 19, 3, 32
+    value = rng.standard_normal((B, S, H, D)).astype(np.float32)
+    for pts in ([6, 6, 8], [16, 0, 0], [1, 0, 0], [5, 5, 6]):
+        P = sum(pts)
+        loc = (rng.random((B, Q, H, P, 2)) * 1.4 - 0.2).astype(np.float32)
+        attn = rng.random((B, Q, H, P)).astype(np.float32)
+        for method in ("default", "discrete"):
+            ref = orc.multi_scale_deformable_attention_v2(value, shapes, loc, attn, pts, method)
+            y = dfine.multi_scale_deformable_attention_v2(_t(value, cuda_device), shapes, _t(loc, cuda_device),
+                                                          _t(attn, cuda_device), pts, method).cpu().numpy()
+            assert np.abs(y - ref).max() <= TOL * max(1.0, np.abs(ref).max()), (pts, method)
+
+
+def test_msda_full_size_properties(cuda_device):
+    """BASELINE config 5 shape (batch 16, 300 queries, 8 heads, 80^2 + 40^2 + 20^2 value map, 3 x 4 points).
+    Linearity in the value map and the constant-map identity out = c * sum(attn) for points well inside."""
+    from defectdetection_viaobjectdetection_amd import dfine
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = [(80, 80), (40, 40), (20, 20)]
+    S, B, Q, H, D, pts = 8400, 16, 300, 8, 32, [4, 4, 4]
+    v1 = torch.randn(B, S, H, D, generator=g).to(cuda_device)
+    v2 = torch.randn(B, S, H, D, generator=g).to(cuda_device)
+    loc = (torch.rand(B, Q, H, 12, 2, generator=g) * 1.2 - 0.1).to(cuda_device)
+    attn = torch.softmax(torch.randn(B, Q, H, 12, generator=g), -1).to(cuda_device)
+    f = lambda v, l=loc: dfine.multi_scale_deformable_attention_v2(v, shapes, l, attn, pts)  # noqa: E731
+    y1, y2, y12 = f(v1), f(v2), f(2.5 * v1 + v2)
+    assert float((y12 - (2.5 * y1 + y2)).abs().max()) <= 1e-4
+    inside = (torch.rand(B, Q, H, 12, 2, generator=g) * 0.8 + 0.1).to(cuda_device)
+    yc = f(torch.full((B, S, H, D), 3.0, device=cuda_device), inside)
+    assert float((yc - 3.0 * attn.sum(-1).repeat_interleave(D, dim=-1).reshape(B, Q, H * D)).abs().max()) <= 1e-5
+    # spot check against the oracle on one batch element
+    import dfine_oracle as orc
+    ref = orc.multi_scale_deformable_attention_v2(v1[:1].cpu().numpy(), shapes, loc[:1].cpu().numpy(), attn[:1].cpu().numpy(), pts)
+    assert np.abs(y1[:1].cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_decode_golden(cuda_device):
+    from defectdetection_viaobjectdetection_amd import dfine
+    proj = dfine.weighting_function(32, torch.tensor([0.5], device=cuda_device), 4.0)
+    np.testing.assert_allclose(proj.cpu().numpy(), G["project"], rtol=2e-6, atol=1e-7)
+    dist, pts = _t(G["dist"], cuda_device), _t(G["points"], cuda_device)
+    d = dfine.integral(dist, proj)
+    np.testing.assert_allclose(d.cpu().numpy(), G["integral"], rtol=1e-5, atol=1e-6)
+    for clamp, key in ((False, "boxes"), (True, "boxes_clamped")):
+        b = dfine.decode_boxes(dist, _t(G["project"], cuda_device), pts, 4.0, clamp01=clamp).cpu().numpy()
+        ref = G[key]
+        assert np.array_equal(np.isnan(b), np.isnan(ref)) and np.array_equal(np.isinf(b), np.isinf(ref)), key
+        fin = np.isfinite(ref)
+        # distances come out of a softmax over 33 bins (exp differs by an ulp); boxes are O(1)
+        np.testing.assert_allclose(b[fin], ref[fin], rtol=1e-5, atol=1e-5)
+    bb = dfine.distance2bbox(pts, d, 4.0).cpu().numpy()
+    fin = np.isfinite(G["boxes"])
+    np.testing.assert_allclose(bb[fin], G["boxes"][fin], rtol=1e-5, atol=1e-5)
+
+
+def test_bad_arguments(cuda_device):
+    from defectdetection_viaobjectdetection_amd import dfine
+    v = torch.zeros(1, 25, 2, 32, device=cuda_device)
+    loc, attn = torch.zeros(1, 3, 2, 4, 2, device=cuda_device), torch.zeros(1, 3, 2, 4, device=cuda_device)
+    with pytest.raises(ValueError):
+        dfine.multi_scale_deformable_attention_v2(v, [(4, 4)], loc, attn, [4])            # 16 != 25
+    with pytest.raises(ValueError):
+        dfine.multi_scale_deformable_attention_v2(v, [(5, 5)], loc, attn, [3])            # points do not add up
+    with pytest.raises(RuntimeError):
+        dfine.multi_scale_deformable_attention_v2(torch.zeros(1, 25, 2, 16, device=cuda_device), [(5, 5)], loc, attn, [4])  # head_dim
+    with pytest.raises(RuntimeError):
+        dfine.multi_scale_deformable_attention_v2(v.cpu(), [(5, 5)], loc, attn, [4])      # no CPU path
