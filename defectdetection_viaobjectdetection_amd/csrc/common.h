@@ -59,7 +59,7 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_LEAN = 21, TILE_LEAN128x8 = 22, TILE_LEAN64x16 = 23, TILE_LEAN128x16 = 24 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_LEAN = 21, TILE_LEAN128x8 = 22, TILE_LEAN64x16 = 23, TILE_LEAN128x16 = 24, TILE_SLAB = 25 };
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {
@@ -81,6 +81,9 @@ int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // vari
 // 128 ch x 16x16 px, K depth 32 per step (conv3x3_wide.hip)
 bool conv3x3_wide_ok(const ConvArgs& a);
 int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s);
+// narrow maps (W <= 26): slabs of full-width rows, linear pixel groups (conv3x3_small.hip)
+bool conv3x3_slab_ok(const ConvArgs& a);
+int launch_conv3x3_slab(const ConvArgs& a, hipStream_t s);
 // D-FINE decoder ops (dfine_kernels.hip)
 int launch_msda(const float* value, const float* loc, const float* attn, float* out, int B, int S, int H, int D, int Q, int P,
                 int L, const int* shapes_hw, const int* points_per_level, int discrete, hipStream_t s);

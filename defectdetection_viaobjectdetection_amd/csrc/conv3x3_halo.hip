@@ -370,6 +370,7 @@ bool conv3x3_halo_ok(const ConvArgs& a) {
 int launch_conv3x3_halo(const ConvArgs& a0, int variant, hipStream_t s) {
   ConvArgs a = a0;
   if (knobs().no_fast_epi) a.dbg |= 256;
+  if (variant == TILE_SLAB - TILE_HALO) return launch_conv3x3_slab(a, s);
   if (!conv3x3_halo_ok(a)) return -1;
   if (variant == 3 || (variant == 0 && conv3x3_wide_ok(a) && !knobs().no_wide)) return launch_conv3x3_wide(a, s);
   if (variant >= 5) return launch_conv3x3_lean(a, variant - 5, s);

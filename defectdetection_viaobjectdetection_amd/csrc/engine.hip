@@ -623,9 +623,13 @@ void annotate_ops(m355_engine* e) {
           wide = op.tile == TILE_HALO && conv3x3_wide_ok(probe) && !getenv("M355_NO_WIDE");
           probe.Kpad = p.Kpad;
           if (op.kind == OP_CONV && conv3x3_c32_ok(probe) && !getenv("M355_NO_C32")) op.tile = TILE_C32;
+          if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
+            op.tile = TILE_SLAB;
         }
         if (op.tile == TILE_C32)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c32<32ch,16x16px>");
+        else if (op.tile == TILE_SLAB)
+          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_slab<64ch,rows>");
         else if (wide)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_wide<128ch,16x16px>");
         else if (op.tile == TILE_HALO && getenv("M355_LEAN"))
@@ -972,7 +976,8 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         }
         a.M = B * a.Ho * a.Wo;
         rc = (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
-             : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s) : launch_conv_igemm(a, op.tile, s));
+             : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
+                                    : (op.tile == TILE_SLAB ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, op.tile, s)));
         break;
       }
       case OP_POOL: {

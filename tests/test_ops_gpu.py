@@ -89,6 +89,13 @@ CONV_CASES = [
     (2, 32, 32, 128, 128, 3, 1, 1, True, 24),
     (3, 48, 32, 192, 256, 3, 1, 0, False, 24),
     (2, 40, 40, 256, 64, 3, 1, 1, False, 21),       # by shape: Cout <= 64 -> 64-channel block
+    # slab kernel for narrow maps (25): R full-width rows x 64 channels, linear pixel groups
+    (2, 20, 20, 256, 256, 3, 1, 1, True, 25),       # the 20x20 C2f layers: two slabs of 10 rows, 12.5 groups
+    (3, 20, 20, 512, 224, 3, 1, 0, False, 25),      # fused head-level convs: ragged channel tile (224 = 3 x 64 + 32)
+    (2, 10, 10, 64, 64, 3, 1, 1, False, 25),        # one slab of 100 pixels = 6.25 groups (waves 2 and 3 mostly idle)
+    (1, 26, 26, 64, 128, 3, 1, 1, True, 25),        # widest map: R = 9, last slab 8 rows
+    (2, 13, 7, 128, 64, 3, 1, 1, False, 25),        # odd sizes, groups straddling up to three rows
+    (300, 20, 20, 64, 64, 3, 1, 1, False, 25),      # 600 tiles on 512 slots: blocks walk two tiles
 ]
 
 

@@ -37,6 +37,9 @@ def run(B, H, W, cin, cout, k, mfma_per_wave):
               f" MFMA share 2 x {mfma_per_wave * 16} / that = {2 * mfma_per_wave * 16 / np.median(tot / nt):.2f}")
     print(f"   cycles med: prologue {np.median(pro):.0f} main {np.median(main):.0f} epilogue {np.median(epi):.0f} total {np.median(tot):.0f};"
           f" MFMA cycles/wave {mfma_per_wave * 16} -> x2 waves/SIMD = {2 * mfma_per_wave * 16 / np.median(main):.2f} of the main loop")
+if tile == 25:   # slab kernel: 20x20 maps, 72 steps x 16 MFMAs per wave
+    run(32, 20, 20, 256, 256, 3, 72 * 16)
+    sys.exit(0)
 run(32, 160, 160, 128, 128, 3, 18 * 32)
 if tile != 19:
     run(32, 40, 40, 128, 128, 3, 18 * 32)
