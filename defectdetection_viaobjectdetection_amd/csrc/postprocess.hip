@@ -149,10 +149,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Mask assembly (A12).  One 256-thread block per (image, 8-row x 32-column tile of the prototype grid = 32 x 128
-// output pixels: a block's stores are whole 128-byte lines of a mask row; the first version used 16 x 16 cells = 64-byte
-// row pieces and wrote at 1.5 TB/s):
-//   1. the 10x34x32 prototype patch (tile + 1-cell halo, border cells replicated = the reference's index
+// Mask assembly (A12).  One 256-thread block per (image, 16x16 tile of the prototype grid):
+//   1. the 18x18x32 prototype patch (tile + 1-cell halo, border cells replicated = the reference's index
 //      clamping) is staged ONCE in LDS and shared by every detection of the image;
 //   2. detections are processed 16 at a time: logits[det][cell] = coef[det] . proto[cell] is one
 //      v_mfma_f32_16x16x32_f16 per 16 cells (coefficients split into fp16 hi + lo parts, two MFMAs, so the
@@ -163,10 +161,8 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, in
 //      thread turns 6 cells x 2 rows into 16 output pixels = one 16-byte store.
 // Detections whose box does not touch the tile's halo window get zero-filled without touching LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int MK_TY = 8, MK_TX = 32;     // tile of the prototype grid
-constexpr int MK_PW = MK_TX + 2;         // patch width (1-cell halo)
-constexpr int MK_CELLS = (MK_TY + 2) * MK_PW;           // 340
-constexpr int MK_CELLS_PAD = (MK_CELLS + 15) / 16 * 16;  // 352: whole 16-cell MFMA column blocks
+constexpr int MK_CELLS = 18 * 18;        // 324
+constexpr int MK_CELLS_PAD = 21 * 16;    // 336: whole 16-cell MFMA column blocks
 constexpr int MK_LG_PITCH = MK_CELLS_PAD + 4;
 
 template <int NM>
@@ -182,7 +178,7 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
   int n = counts[b];
   if (n > max_det) n = max_det;
   if (n <= 0) return;
-  const int tiles_x = (mw + MK_TX - 1) / MK_TX;
+  const int tiles_x = (mw + 15) / 16;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
@@ -193,8 +189,8 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
     const int cell = i >> 2, ch = i & 3;
     half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
     if (cell < MK_CELLS) {
-      const int ly = cell / MK_PW, lx = cell - ly * MK_PW;
-      int y = ty * MK_TY - 1 + ly, x = tx * MK_TX - 1 + lx;
+      const int ly = cell / 18, lx = cell - ly * 18;
+      int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
       y = y < 0 ? 0 : (y >= mh ? mh - 1 : y);
       x = x < 0 ? 0 : (x >= mw ? mw - 1 : x);
       v = *(const half8*)(pb + ((long)y * mw + x) * NM + ch * 8);
@@ -202,10 +198,10 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
     *(half8*)(patch + cell * NM + ch * 8) = v;
   }
   // halo window of this tile in prototype-grid coordinates (for the box-touch test)
-  const float wx0 = (float)(tx * MK_TX - 1), wx1 = (float)(tx * MK_TX + MK_TX), wy0 = (float)(ty * MK_TY - 1),
-              wy1 = (float)(ty * MK_TY + MK_TY);
-  const int oy = tid >> 3, seg = tid & 7;       // 32 output rows x 8 pieces of 16 pixels
-  const int Y = ty * (4 * MK_TY) + oy, X0 = tx * (4 * MK_TX) + seg * 16;
+  const float wx0 = (float)(tx * 16 - 1), wx1 = (float)(tx * 16 + 16), wy0 = (float)(ty * 16 - 1),
+              wy1 = (float)(ty * 16 + 16);
+  const int oy = tid >> 2, seg = tid & 3;
+  const int Y = ty * 64 + oy, X0 = tx * 64 + seg * 16;
   const int qy = oy >> 2, ry = oy & 3;
   const int r0 = (ry < 2) ? qy : qy + 1;
   const float ly1 = (ry == 0) ? 0.625f : (ry == 1) ? 0.875f : (ry == 2) ? 0.125f : 0.375f;
@@ -239,8 +235,8 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
         float4v acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bf, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bf, acc, 0, 0, 0);
-        const int ly = cell / MK_PW, lx = cell - ly * MK_PW;
-        int y = ty * MK_TY - 1 + ly, x = tx * MK_TX - 1 + lx;
+        const int ly = cell / 18, lx = cell - ly * 18;
+        int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
         y = y < 0 ? 0 : (y >= mh ? mh - 1 : y);
         x = x < 0 ? 0 : (x >= mw ? mw - 1 : x);
         const float xf = (float)x, yf = (float)y;
@@ -259,10 +255,10 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
         const bool touches = !(wx1 < bxs[d][0] || wx0 >= bxs[d][2] || wy1 < bxs[d][1] || wy0 >= bxs[d][3]);
         uint8_t o[16];
         if (touches) {
-          const float* l0 = lg + d * MK_LG_PITCH + r0 * MK_PW + seg * 4;
+          const float* l0 = lg + d * MK_LG_PITCH + r0 * 18 + seg * 4;
           float cv[6];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) cv[c] = ly0 * l0[c] + ly1 * l0[MK_PW + c];
+          for (int c = 0; c < 6; ++c) cv[c] = ly0 * l0[c] + ly1 * l0[18 + c];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float a0 = cv[q], a1 = cv[q + 1], a2 = cv[q + 2];
@@ -319,7 +315,7 @@ int launch_proto_masks(const float* dets, const int* counts, const half_t* proto
                        int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s) {
   if (nm != 32) return -1;
   if (in_h % mh || in_w % mw || in_w / mw != 4 || in_h / mh != 4 || in_w % 16) return -1;
-  const int tiles = ((mw + MK_TX - 1) / MK_TX) * ((mh + MK_TY - 1) / MK_TY);
+  const int tiles = ((mw + 15) / 16) * ((mh + 15) / 16);
   hipLaunchKernelGGL(proto_masks_kernel<32>, dim3(tiles, B), dim3(256), 0, s, dets, counts, protos, max_det, mh, mw,
                      in_h, in_w, masks);
   return (int)hipGetLastError();
