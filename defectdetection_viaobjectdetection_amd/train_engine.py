@@ -224,33 +224,34 @@ class TrainEngine:
     def trainable(self) -> List[Tuple[str, torch.Tensor, torch.Tensor]]:
         return [(k, self.params[k], self.grads[k]) for k in self.grads]
 
-    @staticmethod
-    def _pad_pack(m: torch.Tensor) -> torch.Tensor:
-        rows, K = m.shape
-        out = torch.zeros((_ceil(rows, 128), _ceil(K, 64)), dtype=torch.float16, device=m.device)
-        out[:rows, :K] = m.half()
-        return out
+    def _pack_view(self, key: str, rows: int, K: int, shape) -> torch.Tensor:
+        """View of shape `shape` (rows x K elements, row-major) onto the top-left corner of the fp16
+        [rows padded to 128][K padded to 64] GEMM matrix of `key` (allocated and zeroed on first use).  A re-pack is
+        then ONE strided convert-copy per layout into this view instead of ~8 small launches and an allocation."""
+        out = self.packed.get(key)
+        if out is None:
+            out = torch.zeros((_ceil(rows, 128), _ceil(K, 64)), dtype=torch.float16, device=self.dev)
+            self.packed[key] = out
+        return out[:rows, :K].view(shape)
 
     def repack(self) -> None:
-        """fp32 master weights -> fp16 GEMM layouts: forward [Cout][(kh,kw,ci)] and dgrad [Cin][(kh',kw',co)]."""
+        """fp32 master weights -> fp16 GEMM layouts: forward [Cout][(kh,kw,ci)] and dgrad [Cin][(kh',kw',co)].
+        Padded rows / channels (stem 3 -> 8 input channels, nc -> 8 class rows) stay zero from the allocation."""
         for s in self.specs.values():
             if s.transposed:
                 w = self.params[f"{s.name}.weight"]                       # (cin, cout, 2, 2)
-                self.packed[s.name + ":fwd"] = self._pad_pack(w.permute(2, 3, 1, 0).reshape(4 * s.cout, s.cin))
-                self.packed[s.name + ":dgrad"] = self._pad_pack(w.permute(0, 2, 3, 1).reshape(s.cin, 4 * s.cout))
+                self._pack_view(s.name + ":fwd", 4 * s.cout, s.cin, (2, 2, s.cout, s.cin)).copy_(w.permute(2, 3, 1, 0))
+                self._pack_view(s.name + ":dgrad", s.cin, 4 * s.cout, (s.cin, 2, 2, s.cout)).copy_(w.permute(0, 2, 3, 1))
                 continue
             w = self.params[f"{s.name}.conv.weight" if s.has_bn else f"{s.name}.weight"]  # (cout, k, k, cin)
-            cout, cin = s.cout, s.cin
-            if cin == 3:                                                    # stem: input padded to 8 channels
-                w = F.pad(w, (0, 5))
-                cin = 8
-            if cout % 8:                                                    # class branch (nc) -> pad rows to 8
-                w = F.pad(w, (0, 0, 0, 0, 0, 0, 0, _ceil(cout, 8) - cout))
-                cout = _ceil(cout, 8)
-            self.packed[s.name + ":fwd"] = self._pad_pack(w.reshape(cout, -1))
+            k = s.k
+            cin_p = 8 if s.cin == 3 else s.cin                              # stem: input padded to 8 channels
+            cout_p = _ceil(s.cout, 8)                                       # class branch (nc) -> rows padded to 8
+            self._pack_view(s.name + ":fwd", cout_p, k * k * cin_p, (cout_p, k, k, cin_p))[:s.cout, :, :, :s.cin].copy_(w)
             if s.cin != 3:
                 wd = w if s.stride == 2 else w.flip(1, 2)                   # stride 2 = transposed-stride gather, no flip
-                self.packed[s.name + ":dgrad"] = self._pad_pack(wd.permute(3, 1, 2, 0).reshape(cin, -1))
+                self._pack_view(s.name + ":dgrad", cin_p, k * k * cout_p, (cin_p, k, k, cout_p))[..., :s.cout].copy_(
+                    wd.permute(3, 1, 2, 0))
 
     # ------------------------------------------------------------------ kernel plumbing
     def _stream(self):
