@@ -98,7 +98,8 @@ def segmentation_loss(raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, 
     logits_box, logits_cls, coefs = raw.split((4 * REG_MAX, nc, NM), 2)
     anchors, strides = anchor_grid(imgsz, dev)
     bins = torch.arange(REG_MAX, device=dev, dtype=torch.float32)
-    ltrb = logits_box.view(B, A, 4, REG_MAX).softmax(3) @ bins
+    # expectation over the 16 bins as multiply + reduce: `softmax @ bins` runs as a (B*A*4) x 16 rocBLAS gemv, 1.4 ms
+    ltrb = (logits_box.view(B, A, 4, REG_MAX).softmax(3) * bins).sum(3)
     pred_boxes = torch.cat((anchors - ltrb[..., :2], anchors + ltrb[..., 2:]), -1)   # grid units
     # padded GT tensors
     bidx = batch["batch_idx"].to(dev).long()

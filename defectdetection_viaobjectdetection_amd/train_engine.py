@@ -453,11 +453,12 @@ class TrainEngine:
             elif kind == "pool":                                           # SPPF: y1 = mp(a), y2 = mp(y1), y3 = mp(y2)
                 src, dst = op["src"], op["dst"]
                 c = src.c
-                a = self.tensors[src.t][..., src.off:src.off + c].permute(0, 3, 1, 2).float().requires_grad_(True)
+                # contiguous NCHW copies: on the permuted (channels-last) views torch picks max_pool_backward_nhwc, 0.6 ms a call
+                a = self.tensors[src.t][..., src.off:src.off + c].permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)
                 y1 = F.max_pool2d(a, 5, 1, 2)
                 y2 = F.max_pool2d(y1, 5, 1, 2)
                 y3 = F.max_pool2d(y2, 5, 1, 2)
-                g = self.gtensors[dst.t][..., dst.off:dst.off + 3 * c].permute(0, 3, 1, 2).float()
+                g = self.gtensors[dst.t][..., dst.off:dst.off + 3 * c].permute(0, 3, 1, 2).float().contiguous()
                 (ga,) = torch.autograd.grad((y1, y2, y3), a, (g[:, :c], g[:, c:2 * c], g[:, 2 * c:]))
                 self._gview(src).add_(ga.permute(0, 2, 3, 1).half())
             elif kind == "up":
