@@ -333,6 +333,78 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     if (a.stamps && tile == lb) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
+    const float* bias_fin = a.bias;   // bias of the conv whose output is stored
+    if (KS != 2 && MT == 4 && !a.phase && a.w2) {
+      // Conv + the 1x1 conv that is its only consumer (C2f.cv1 after a stride-2 conv) in one launch: the tile holds ALL
+      // channels of its pixels (Cout == BCH == cout2, checked by the launcher), so Z = SiLU(conv + bias) goes to LDS as fp16
+      // [pixel][BCH] instead of HBM, the BCH x BCH weights of the 1x1 conv beside it, and every wave multiplies its own
+      // 64 ch x (NT x 16) px block with K = BCH in the K order of the stand-alone 1x1 launch (same bits).  acc is replaced
+      // by the result; the ordinary epilogue below stores it with the second bias.
+      constexpr int ROW2 = BCH * 2, CH2 = BCH / 8;          // bytes and 16-byte chunks per LDS row
+      __syncthreads();                                      // every wave is done with the K-loop stages
+      char* const zb = smem;                                // BPX rows
+      char* const wb2 = smem + BPX * ROW2;                  // BCH rows: LDS row R <- logical channel chl(R), as the loader does
+      for (int i = tid; i < BCH * CH2; i += NW * 64) {
+        const int R = i / CH2, c = i - R * CH2;
+        const int blk = R >> 6, Rl = R & 63, mt2 = Rl >> 4, r = Rl & 15;
+        const int chl = blk * 64 + (mt2 >> 1) * 32 + (r >> 2) * 8 + (mt2 & 1) * 4 + (r & 3);
+        *(float4v*)(wb2 + R * ROW2 + ((c ^ (R & (CH2 - 1))) << 4)) = *(const float4v*)(a.w2 + (long)chl * BCH + c * 8);
+      }
+      const float* bp = a.bias + wch * 64 + g * 8;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int p = wpx * NT * 16 + nt * 16 + l15;        // pixel inside the tile
+#pragma unroll
+        for (int sg = 0; sg < 2; ++sg) {
+          const float4v b0 = *(const float4v*)(bp + sg * 32), b1 = *(const float4v*)(bp + sg * 32 + 4);
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            float v0 = acc[2 * sg][nt][j] + b0[j], v1 = acc[2 * sg + 1][nt][j] + b1[j];
+            if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); }
+            o[j] = m355_to_half(v0);
+            o[4 + j] = m355_to_half(v1);
+          }
+          const int c = (wch * 64 + sg * 32 + g * 8) >> 3;
+          *(half8*)(zb + p * ROW2 + ((c ^ (p & (CH2 - 1))) << 4)) = o;
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = float4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < BCH / 32; ++ks) {
+        half8 a2[MT], b2[NT];
+        const int c = ks * 4 + g;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const int R = wch * 64 + mt * 16 + l15;
+          a2[mt] = *(const half8*)(wb2 + R * ROW2 + ((c ^ (R & (CH2 - 1))) << 4));
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const int p = wpx * NT * 16 + nt * 16 + l15;
+          b2[nt] = *(const half8*)(zb + p * ROW2 + ((c ^ (p & (CH2 - 1))) << 4));
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[mt], b2[nt], acc[mt][nt], 0, 0, 0);
+      }
+      __syncthreads();                                      // the stages are reused by the next tile (persistent mode)
+      bias_fin = a.bias2;
+      if (fast) {
+        const float* bq = a.bias2 + wch * MT * 16 + g * 8;
+#pragma unroll
+        for (int sg = 0; sg < MT / 2; ++sg) {
+          bv[sg][0] = *(const float4v*)(bq + sg * 32);
+          bv[sg][1] = *(const float4v*)(bq + sg * 32 + 4);
+        }
+      }
+    }
     if (KS == 2 && MT == 4 && NT == 4 && WCH == 2 && a.phase && a.w2) {
       // Phase conv + proto.cv3 in one epilogue.  The 128 ch x 128 px tile Z = SiLU(phase conv) goes to LDS as fp16
       // [pixel][128 ch] (16-byte chunk c of pixel p in slot c ^ (p & 15): conflict-free for the writes below and for the
@@ -522,7 +594,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
           yoff = (long)b * a.y_bstride + (long)pix * a.ldy + ch0;
         }
 #pragma unroll
-        for (int j = 0; j < GW; ++j) v[j] += a.bias[cidx + j];
+        for (int j = 0; j < GW; ++j) v[j] += bias_fin[cidx + j];
         if (a.act && !(a.dbg & 32)) {
 #pragma unroll
           for (int j = 0; j < GW; ++j) v[j] = silu_f(v[j]);
@@ -656,7 +728,12 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
   if (a.ksize == 2 && a.phase && ((tile == TILE_128x128 && a.convt_co % 128) || (tile != TILE_128x128 && tile != TILE_64x128)))
     return -1;   // a channel tile must lie inside one phase
-  if (a.w2 && !(a.ksize == 2 && a.phase && tile == TILE_128x128 && a.convt_co == 128 && a.cout2 == 32 && a.bias2)) return -1;
+  if (a.w2 && a.phase && !(a.ksize == 2 && tile == TILE_128x128 && a.convt_co == 128 && a.cout2 == 32 && a.bias2)) return -1;
+  // conv + following 1x1 in one launch: one channel tile holding every channel, square 1x1, fp16 out
+  if (a.w2 && !a.phase &&
+      !(a.ksize != 2 && a.bias2 && !a.out_f32 && a.convt_co == 0 && !a.tmode && a.cout2 == a.Cout &&
+        ((tile == TILE_128x128 && a.Cout == 128) || (tile == TILE_64x128 && a.Cout == 64))))
+    return -1;
   switch (tile) {
     case TILE_128x128: return launch_variant<4, 4, 2, 2>(a, s);
     case TILE_64x128: return launch_variant<4, 2, 1, 4>(a, s);

@@ -462,6 +462,47 @@ int build_graph(m355_engine* e) {
   return 0;
 }
 
+// A stride-2 backbone conv whose ONLY consumer is the 1x1 cv1 of the following C2f, with as many channels as one
+// im2col channel tile holds (64 or 128) on both sides: the 1x1 runs in the conv kernel's epilogue through LDS and the
+// conv's own output never goes to HBM (model.1 -> model.2.cv1 and model.3 -> model.4.cv1 for the s scale).
+void fuse_conv_cv1(m355_engine* e) {
+  if (getenv("M355_NO_CVFUSE")) return;
+  for (size_t i = 0; i < e->ops.size(); ++i) {
+    Op& oi = e->ops[i];
+    if (oi.kind != OP_CONV || oi.out_ext != 0 || oi.res.t >= 0 || oi.in2.t >= 0) continue;
+    PhysConv& pi = e->phys[oi.conv];
+    if (pi.k != 3 || pi.stride != 2 || pi.logical.size() != 1 || pi.diag || pi.composed || pi.l3 >= 0 || !pi.act) continue;
+    const int C = pi.cout;
+    if (C != 64 && C != 128) continue;
+    const Tensor& to = e->tensors[oi.out.t];
+    // the kernel needs the tile that holds every channel: the same rule annotate_ops applies
+    if (conv_pick_tile(C, (long)e->desc.max_batch * to.H * to.W) != (C == 128 ? TILE_128x128 : TILE_64x128)) continue;
+    int j = -1, readers = 0;
+    for (size_t k = 0; k < e->ops.size(); ++k) {
+      const Op& ok = e->ops[k];
+      if (ok.in.t == oi.out.t || ok.in2.t == oi.out.t || ok.res.t == oi.out.t) {
+        ++readers;
+        j = (int)k;
+      }
+    }
+    if (readers != 1 || j <= (int)i) continue;
+    const Op& oj = e->ops[j];
+    if (oj.kind != OP_CONV || oj.in.t != oi.out.t || oj.in.off != oi.out.off || oj.in.c != C || oj.in2.t >= 0 || oj.res.t >= 0 ||
+        oj.out_ext != 0)
+      continue;
+    const PhysConv& pj = e->phys[oj.conv];
+    if (pj.k != 1 || pj.stride != 1 || pj.logical.size() != 1 || pj.diag || pj.cout != C || pj.cin != C || !pj.act) continue;
+    const int lj = pj.logical[0];
+    pi.l3 = lj;
+    pi.cout2 = C;
+    pi.logical.push_back(lj);
+    e->conv_phys[lj] = oi.conv;
+    oi.out = oj.out;
+    oi.lane = oj.lane;
+    e->ops.erase(e->ops.begin() + j);
+  }
+}
+
 // Producers of op i in the current op order: earlier ops that write a tensor it reads; the decode reads the raw head map.
 std::vector<int> op_producers(const m355_engine* e, int i) {
   const Op& op = e->ops[i];
@@ -569,7 +610,7 @@ int alloc_all(m355_engine* e) {
     HIP_TRY(e, hipMalloc((void**)&p.w, wb));
     HIP_TRY(e, hipMemset(p.w, 0, wb));
     if (p.l3 >= 0) {
-      HIP_TRY(e, hipMalloc((void**)&p.w2, (size_t)p.cout2 * p.cin * sizeof(half_t)));
+      HIP_TRY(e, hipMalloc((void**)&p.w2, (size_t)p.cout2 * p.cout * sizeof(half_t)));   // K of the 1x1 = p.cout
       HIP_TRY(e, hipMalloc((void**)&p.bias2, (size_t)p.cout2 * sizeof(float)));
     }
     const size_t nbias = p.composed ? (size_t)9 * p.cout : (size_t)p.cout_pad;   // composed: [9 border classes][cout]
@@ -638,6 +679,11 @@ void annotate_ops(m355_engine* e) {
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_halo<%s>", cout_v > 64 ? "128ch" : "64ch");
         else
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d>", tile_names[op.tile], k);
+        if (op.kind == OP_CONV && p.l3 >= 0) {   // + the 1x1 conv in the epilogue
+          snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d+1x1>", tile_names[op.tile], k);
+          snprintf(op.layer, sizeof(op.layer), "%s+%s", e->convs[p.logical[0]].name, e->convs[p.l3].name);
+          op.flops += 2.0 * Ho * Wo * (double)p.cout * p.cout2;
+        }
         op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)Ho * Wo * cout_v * (op.out_ext == 1 ? 4 : 2) +
                    (op.res.t >= 0 ? (double)Ho * Wo * cout_v * 2 : 0.0);
         if (op.in2.t >= 0)   // the read-through part is a quarter-size tensor
@@ -725,6 +771,7 @@ int m355_create(const m355_model_desc* desc, m355_engine** out) {
   m355_engine* e = new m355_engine();
   e->desc = *desc;
   int rc = build_graph(e);
+  if (rc == 0) fuse_conv_cv1(e);
   if (rc == 0) rc = plan_lanes(e);
   if (rc == 0) rc = alloc_all(e);
   if (rc == 0) annotate_ops(e);
@@ -781,8 +828,8 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
   const m355_conv_info& ci = e->convs[idx];
   PhysConv& p = e->phys[e->conv_phys[idx]];
   const int row0 = e->conv_phys_off[idx];
-  if (p.composed && idx == p.l3) {   // proto.cv3 in the phase conv's epilogue: plain fp16 [cout2][cin] + bias
-    std::vector<half_t> r2((size_t)p.cout2 * p.cin);
+  if (idx == p.l3) {   // a 1x1 conv applied in its producer's epilogue (proto.cv3, C2f.cv1 after a stride-2 conv): plain fp16 [cout2][K] + bias
+    std::vector<half_t> r2((size_t)p.cout2 * p.cout);
     for (size_t i = 0; i < r2.size(); ++i) r2[i] = (half_t)w[i];
     HIP_TRY(e, hipMemcpy(p.w2, r2.data(), r2.size() * sizeof(half_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias2, bias, p.cout2 * sizeof(float), hipMemcpyHostToDevice));
@@ -975,6 +1022,10 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           a.res = tr.p + op.res.off; a.r_bstride = (long)tr.H * tr.W * tr.C; a.ldr = tr.C;
         }
         a.M = B * a.Ho * a.Wo;
+        if (op.kind == OP_CONV && e->phys[op.conv].l3 >= 0) {   // following 1x1 conv in this launch's epilogue
+          const PhysConv& pf = e->phys[op.conv];
+          a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2;
+        }
         rc = (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
              : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
                                     : (op.tile == TILE_SLAB ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, op.tile, s)));

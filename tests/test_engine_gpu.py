@@ -265,3 +265,33 @@ def test_stream_lanes_equal_single_stream(cuda_device):
         assert torch.equal(p, ref[i][0]) and torch.equal(q, ref[i][1]), i
     a.close()
     b.close()
+
+
+def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
+    """model.1 -> model.2.cv1 and model.3 -> model.4.cv1 (s scale: 64 and 128 channels = one channel tile) run as one
+    launch each, the 1x1 in the stride-2 conv's epilogue through LDS; M355_NO_CVFUSE runs them separately.  The fp16
+    intermediate and the K order of the 1x1 are the same in both forms: identical bits.  At the n scale the 64-channel
+    pair is model.3 -> model.4.cv1; its 128-channel pair has too few pixels here for the 128-channel tile."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    for scale, nfused in (("s", 2), ("n", 1)):
+        sd = synthetic_state_dict(scale, 1, seed=0)
+        # 7 images of 608 x 640: the 76 x 80 map of model.3 gives 332.5 pixel tiles (a partial one), enough for the 128-channel tile
+        imgs = torch.from_numpy(synthetic_bscans(7, seed=31)[:, :608, :].copy()).to(cuda_device)
+        outs = []
+        for fuse in (True, False):
+            if not fuse:
+                os.environ["M355_NO_CVFUSE"] = "1"
+            try:
+                eng = SegEngine(scale, 1, (608, 640), max_batch=7)
+            finally:
+                os.environ.pop("M355_NO_CVFUSE", None)
+            kinds = [o["kernel"] for o in eng.op_infos()]
+            assert sum("+1x1>" in k and "phase" not in k for k in kinds) == (nfused if fuse else 0), kinds
+            eng.load_state_dict(sd)
+            p, q = eng.forward(imgs)
+            torch.cuda.synchronize()
+            outs.append((p.clone(), q.clone()))
+            eng.close()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), scale
