@@ -139,7 +139,9 @@ def main():
     sampled = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        on = profile and (i % args.profile_every == args.profile_every // 2 or args.steps < args.profile_every)
+        # every n-th step; a run shorter than n samples its middle step only (sampled steps give up all overlap)
+        on = profile and (i % args.profile_every == args.profile_every // 2 or
+                          (args.steps < args.profile_every and i == args.steps // 2))
         cur = engs[step_no[0] % n_eng]
         if on:
             cur.set_profiling(True)
