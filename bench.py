@@ -39,7 +39,7 @@ def main():
                     help="engine instances (own activations and streams) that take the batches in turn: two batches "
                          "are in flight, the small-map tail of one forward runs beside the large-map start of the next")
     ap.add_argument("--serial", action="store_true",
-                    help="one engine, one stream lane inside it (M355_NO_LANES): every kernel runs alone, so rocprofv3's "
+                    help="one engine, one stream lane inside it (M355_NO_LANES), whole-batch launches (M355_NO_SUBBATCH): every kernel runs alone, so rocprofv3's "
                          "per-kernel averages and the live event samples describe the same launches")
     ap.add_argument("--profile-every", type=int, default=10,
                     help="record per-op HIP events on every n-th timed step (an event pair per launch costs "
@@ -69,6 +69,7 @@ def main():
     sd = synthetic_state_dict(args.scale, 1, seed=0)
     if args.serial:
         os.environ["M355_NO_LANES"] = "1"
+        os.environ["M355_NO_SUBBATCH"] = "1"
         args.engines = 1
     n_eng = max(1, args.engines)
     engs = []

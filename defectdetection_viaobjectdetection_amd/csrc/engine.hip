@@ -110,6 +110,9 @@ struct m355_engine {
   std::vector<hipStream_t> side;      // lanes 1 .. nlanes-1
   std::vector<hipEvent_t> op_done;    // one per op with record == true (else nullptr)
   std::vector<int> lane_last;         // last op of every lane (joined into the caller's stream at the end of a forward)
+  // sub-batches: the leading large-map ops run over `sub_batch` images at a time, so that a tensor (26-52 MB instead of
+  // 105-210 MB at batch 32) is still in the 256 MiB Infinity Cache when its consumer reads it
+  int sub_batch = 0, sub_ops = 0;
   // profiling: HIP events around every op launch, recorded on the caller's stream (single lane while profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;   // 2 events per op per recorded forward
@@ -519,6 +522,24 @@ std::vector<int> op_producers(const m355_engine* e, int i) {
   return r;
 }
 
+// Sub-batched segment: the leading ops (stem, the stride-2 convs, the 160x160 and 80x80 C2f stages) while they are plain
+// convs on the caller's lane whose output map is at least 1/8 of the input.  M355_SUBBATCH = images per pass (default 0: off),
+// M355_SUBBATCH_OPS = number of leading ops.
+void plan_sub_batches(m355_engine* e) {
+  const char* sb = getenv("M355_SUBBATCH");
+  e->sub_batch = sb ? atoi(sb) : 0;   // measured at batch 32 with two engines in flight: 8 -> -5 %, 16 -> -2 %: off by default
+  if (e->sub_batch <= 0 || getenv("M355_NO_SUBBATCH")) { e->sub_batch = 0; return; }
+  int n = 0;
+  for (const Op& op : e->ops) {
+    if ((op.kind != OP_STEM && op.kind != OP_CONV) || op.lane != 0 || op.record || !op.wait_ops.empty() || op.out_ext != 0) break;
+    const Tensor& to = e->tensors[op.out.t];
+    if (to.H * 8 < e->desc.in_h) break;
+    ++n;
+  }
+  if (const char* so = getenv("M355_SUBBATCH_OPS")) n = std::min(n, atoi(so));
+  e->sub_ops = n;
+}
+
 // Stream lanes.  The builder tags the ops of Proto and of the stride-8 head level with lane 1; everything else is
 // lane 0 (the caller's stream).  (1) Reorder: a lane-1 op moves to right after the last lane-0 op it depends on, so the
 // host enqueues it as early as the data allows (lane order is kept, so the result is still a topological order).
@@ -773,6 +794,7 @@ int m355_create(const m355_model_desc* desc, m355_engine** out) {
   int rc = build_graph(e);
   if (rc == 0) fuse_conv_cv1(e);
   if (rc == 0) rc = plan_lanes(e);
+  if (rc == 0) plan_sub_batches(e);
   if (rc == 0) rc = alloc_all(e);
   if (rc == 0) annotate_ops(e);
   if (rc != 0) {
@@ -936,7 +958,9 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
   hipStream_t s_main = (hipStream_t)stream;
   const int rw = 64 + e->nc + e->nm;
   const bool lanes = e->nlanes > 1 && !e->profiling;   // per-op event timing needs one stream
-  for (size_t oi = 0; oi < e->ops.size(); ++oi) {
+  // ops [lo, hi) over images [b0, b0 + Bq)
+  auto run_range = [&](size_t lo, size_t hi, const int b0, const int Bq) -> int {
+  for (size_t oi = lo; oi < hi; ++oi) {
     const Op& op = e->ops[oi];
     int rc = 0;
     hipStream_t s = (lanes && op.lane > 0) ? e->side[op.lane - 1] : s_main;
@@ -957,9 +981,10 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         const PhysConv& p = e->phys[op.conv];
         const Tensor& to = e->tensors[op.out.t];
         StemArgs a{};
-        a.x = (const uint8_t*)d_in; a.B = B; a.H = op.Hi; a.W = op.Wi;
+        a.x = (const uint8_t*)d_in + (long)b0 * op.Hi * op.Wi * 3; a.B = Bq; a.H = op.Hi; a.W = op.Wi;
         a.w16 = (const half_t*)p.stem_w; a.bias = p.bias;
-        a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C; a.Cout = p.cout;
+        a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C; a.Cout = p.cout;
+        a.y = to.p + op.out.off + b0 * a.y_bstride;
         rc = launch_stem(a, s);
         break;
       }
@@ -979,7 +1004,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           const Tensor& to = e->tensors[op.out.t];
           a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
         }
-        a.M = B * a.Ho * a.Wo;
+        a.M = Bq * a.Ho * a.Wo;
         rc = launch_conv_igemm(a, op.tile, s);
         break;
       }
@@ -1021,7 +1046,13 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           const Tensor& tr = e->tensors[op.res.t];
           a.res = tr.p + op.res.off; a.r_bstride = (long)tr.H * tr.W * tr.C; a.ldr = tr.C;
         }
-        a.M = B * a.Ho * a.Wo;
+        a.M = Bq * a.Ho * a.Wo;
+        if (b0) {   // sub-batch: every operand starts b0 images in (external outputs never are in the sub-batched segment)
+          a.x += b0 * a.x_bstride;
+          if (op.out_ext == 0) a.y = (half_t*)a.y + b0 * a.y_bstride;
+          if (a.x2) a.x2 += b0 * a.x2_bstride;
+          if (a.res) a.res += b0 * a.r_bstride;
+        }
         if (op.kind == OP_CONV && e->phys[op.conv].l3 >= 0) {   // following 1x1 conv in this launch's epilogue
           const PhysConv& pf = e->phys[op.conv];
           a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2;
@@ -1034,18 +1065,18 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
       case OP_POOL: {
         const Tensor& t = e->tensors[op.in.t];
         rc = launch_sppf_pool(t.p + op.in.off, (long)t.H * t.W * t.C, t.C, t.p + op.out.off, (long)t.H * t.W * t.C,
-                              t.C, B, t.H, t.W, op.in.c, s);
+                              t.C, Bq, t.H, t.W, op.in.c, s);
         break;
       }
       case OP_UP: {
         const Tensor& ti = e->tensors[op.in.t];
         const Tensor& to = e->tensors[op.out.t];
         rc = launch_upsample2x(ti.p + op.in.off, (long)ti.H * ti.W * ti.C, ti.C, to.p + op.out.off,
-                               (long)to.H * to.W * to.C, to.C, B, ti.H, ti.W, op.in.c, s);
+                               (long)to.H * to.W * to.C, to.C, Bq, ti.H, ti.W, op.in.c, s);
         break;
       }
       case OP_DECODE:
-        rc = launch_head_decode(e->raw, B, e->desc.in_h, e->desc.in_w, e->nc, e->nm, d_preds, s);
+        rc = launch_head_decode(e->raw, Bq, e->desc.in_h, e->desc.in_w, e->nc, e->nm, d_preds, s);
         break;
     }
     if (e->profiling) {
@@ -1055,6 +1086,21 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
     if (rc != 0) return e->fail(M355_ERR_HIP, "kernel launch failed (op kind " + std::to_string((int)op.kind) +
                                                   ", code " + std::to_string(rc) + ")");
     if (lanes && op.record) HIP_TRY(e, hipEventRecord(e->op_done[oi], s));
+  }
+  return M355_OK;
+  };
+  const size_t nops = e->ops.size();
+  size_t first = 0;
+  if (!e->profiling && e->sub_batch > 0 && e->sub_ops > 0 && B > e->sub_batch) {
+    for (int b0 = 0; b0 < B; b0 += e->sub_batch) {
+      const int rcs = run_range(0, (size_t)e->sub_ops, b0, std::min(e->sub_batch, B - b0));
+      if (rcs != M355_OK) return rcs;
+    }
+    first = (size_t)e->sub_ops;
+  }
+  {
+    const int rcs = run_range(first, nops, 0, B);
+    if (rcs != M355_OK) return rcs;
   }
   if (lanes)   // join: everything this forward launched is ordered before whatever the caller enqueues next
     for (int l = 1; l < e->nlanes; ++l)

@@ -295,3 +295,30 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
             outs.append((p.clone(), q.clone()))
             eng.close()
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), scale
+
+
+def test_sub_batched_leading_ops_are_bit_identical(cuda_device):
+    """M355_SUBBATCH=8 runs the large-map ops at the head of the graph over 8 images at a time (an experiment: the tensors
+    then fit the Infinity Cache between producer and consumer; measured slower, so it is off by default).  Same
+    kernels per image: identical bits, also with a ragged last pass (20 = 8 + 8 + 4)."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(20, seed=41)[:, :320, :384].copy()).to(cuda_device)
+    outs = []
+    for sub in (True, False):
+        if sub:
+            os.environ["M355_SUBBATCH"] = "8"
+        try:
+            eng = SegEngine("s", 1, (320, 384), max_batch=20)
+        finally:
+            os.environ.pop("M355_SUBBATCH", None)
+        eng.load_state_dict(sd)
+        p, q = eng.forward(imgs)
+        raw = eng.raw_head(20)
+        torch.cuda.synchronize()
+        outs.append((p.clone(), q.clone(), raw.clone()))
+        eng.close()
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
