@@ -27,8 +27,8 @@ HBM_PEAK_GBS = 8000.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--scale", default="s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="one engine, one stream lane inside it (M355_NO_LANES), whole-batch launches (M355_NO_SUBBATCH): every kernel runs alone, so rocprofv3's "
                          "per-kernel averages and the live event samples describe the same launches")
-    ap.add_argument("--profile-every", type=int, default=10,
+    ap.add_argument("--profile-every", type=int, default=25,
                     help="record per-op HIP events on every n-th timed step (an event pair per launch costs "
                          "~8 us of serialisation, ~0.6 ms per fully instrumented step)")
     args = ap.parse_args()
