@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--engines", type=int, default=2,
                     help="engine instances (own activations and streams) that take the batches in turn: two batches "
                          "are in flight, the small-map tail of one forward runs beside the large-map start of the next")
+    ap.add_argument("--lanes", choices=("auto", "on", "off"), default="auto",
+                    help="stream lanes inside an engine (Proto / head levels on side streams): they gain 4-5 %% with one "
+                         "engine and cost 3 %% once two engines are in flight, so auto = on for one engine, off otherwise")
     ap.add_argument("--serial", action="store_true",
                     help="one engine, one stream lane inside it (M355_NO_LANES), whole-batch launches (M355_NO_SUBBATCH): every kernel runs alone, so rocprofv3's "
                          "per-kernel averages and the live event samples describe the same launches")
@@ -72,6 +75,8 @@ def main():
         os.environ["M355_NO_SUBBATCH"] = "1"
         args.engines = 1
     n_eng = max(1, args.engines)
+    if args.lanes == "off" or (args.lanes == "auto" and n_eng > 1):
+        os.environ["M355_NO_LANES"] = "1"
     engs = []
     for _ in range(n_eng):
         e_ = SegEngine(args.scale, 1, (640, 640), max_batch=B, device=local_rank)
