@@ -79,7 +79,7 @@ def main():
         os.environ["M355_NO_LANES"] = "1"
     engs = []
     for _ in range(n_eng):
-        e_ = SegEngine(args.scale, 1, (640, 640), max_batch=B, device=local_rank)
+        e_ = SegEngine(args.scale, 1, (640, 640), max_batch=B, device=local_rank, keep_raw=False)   # as YOLO.predict does
         e_.load_state_dict(sd)
         engs.append(e_)
     eng = engs[0]

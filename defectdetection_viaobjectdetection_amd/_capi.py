@@ -79,6 +79,7 @@ SIGNATURES = {
     "m355_collect_op_times": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_long)]),
     "m355_get_raw_head": (C.c_int, [_P, C.POINTER(_P), C.POINTER(C.c_int)]),
     "m355_copy_raw_head": (C.c_int, [_P, C.c_int, _P, _P]),
+    "m355_set_keep_raw": (C.c_int, [_P, C.c_int]),
     "m355_postprocess": (C.c_int, [_P, _P, _P, C.c_int, C.c_float, C.c_float, C.c_int, _P, _P, _P, _P]),
     "m355_conv2d_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _P, _P, C.c_int, C.c_int, _P]),

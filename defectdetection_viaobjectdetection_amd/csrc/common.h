@@ -56,6 +56,12 @@ struct ConvArgs {
   const half_t* w2;
   const float* bias2;
   int cout2;
+  // Head output conv + decode in one launch (fp32 1x1 conv whose single 128-channel tile holds the whole 64 + nc + nm row
+  // of a pixel): the DFL expectation, dist2bbox, the class sigmoid and the coefficient copy of head_decode_kernel run in
+  // the epilogue and write the prediction rows; the raw map is written too only when dec_keep_raw is set.
+  float* dec_preds;        // (B, dec_A, 4 + nc + nm) fp32; nullptr: off
+  int dec_A, dec_level_off, dec_nc, dec_nm, dec_keep_raw;
+  float dec_stride;
 };
 
 // tile ids for launch_conv_igemm(force_tile)

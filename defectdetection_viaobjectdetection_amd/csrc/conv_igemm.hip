@@ -405,6 +405,86 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
         }
       }
     }
+    if (KS == 1 && MT == 4 && NT == 4 && WCH == 2 && a.dec_preds) {
+      // Head output conv + decode (the launcher checked: fp32 out, one channel tile, (wi + wo) * 64 floats fit the stages).
+      // Two passes of 64 pixels = the 64-anchor blocks of head_decode_kernel, same arithmetic in the same order: the raw
+      // row of a pixel goes to LDS instead of (or besides) HBM, four threads per anchor decode it, the prediction rows
+      // leave through LDS with coalesced stores.
+      const int nc = a.dec_nc, nm = a.dec_nm, wi = 64 + nc + nm, wo = 4 + nc + nm;
+      float* const sin = (float*)smem;              // [64][wi]
+      float* const sout = sin + 64 * wi;            // [64][wo]
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        __syncthreads();                            // the stages / the previous pass are no longer read
+        if (wpx == half) {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            float* rp = sin + (nt * 16 + l15) * wi;
+#pragma unroll
+            for (int sg = 0; sg < 2; ++sg) {
+              const int ch0 = wch * 64 + sg * 32 + g * 8;
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                if (ch0 + j < wi) rp[ch0 + j] = acc[2 * sg][nt][j] + a.bias[ch0 + j];
+                if (ch0 + 4 + j < wi) rp[ch0 + 4 + j] = acc[2 * sg + 1][nt][j] + a.bias[ch0 + 4 + j];
+              }
+            }
+          }
+        }
+        __syncthreads();
+        const int al_blk = tid >> 2, q = tid & 3;
+        const int m = px_base + half * 64 + al_blk;
+        const bool valid = m < a.M;
+        const float* rp = sin + al_blk * wi;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = rp[q * 16 + j];
+        float mx = v[0];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) mx = fmaxf(mx, v[j]);
+        float se = 0.f, sw = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float e = __expf(v[j] - mx);
+          se += e;
+          sw += e * (float)j;
+        }
+        const float d = sw / se;
+        int bb, al;
+        fast_divmod(valid ? m : 0, HoWo, inv_howo, bb, al);
+        int gy, gx;
+        fast_divmod(al, a.Wo, inv_wo, gy, gx);
+        const float ax = (float)gx + 0.5f, ay = (float)gy + 0.5f;
+        const int lbase = lane & ~3;
+        const float dl = __shfl(d, lbase + 0), dt = __shfl(d, lbase + 1), dr = __shfl(d, lbase + 2), db = __shfl(d, lbase + 3);
+        const float x1 = ax - dl, y1 = ay - dt, x2 = ax + dr, y2 = ay + db;
+        float o;
+        if (q == 0) o = (x1 + x2) * 0.5f;
+        else if (q == 1) o = (y1 + y2) * 0.5f;
+        else if (q == 2) o = x2 - x1;
+        else o = y2 - y1;
+        float* pp = sout + al_blk * wo;
+        pp[q] = o * a.dec_stride;
+        for (int j = q; j < nc; j += 4) {
+          const float z = rp[64 + j];
+          pp[4 + j] = 1.0f / (1.0f + __expf(-z));
+        }
+        for (int j = q; j < nm; j += 4) pp[4 + nc + j] = rp[64 + nc + j];
+        __syncthreads();
+        const float inv_wo2 = 1.0f / (float)wo;
+        for (int i = tid; i < 64 * wo; i += NW * 64) {
+          int r, j;
+          fast_divmod(i, wo, inv_wo2, r, j);
+          const int mr = px_base + half * 64 + r;
+          if (mr >= a.M) continue;
+          int b2, al2;
+          fast_divmod(mr, HoWo, inv_howo, b2, al2);
+          a.dec_preds[((long)b2 * a.dec_A + a.dec_level_off + al2) * wo + j] = sout[i];
+        }
+      }
+      __syncthreads();                              // (persistent mode: the stages are reused by the next tile)
+      if (!a.dec_keep_raw) continue;
+    }
     if (KS == 2 && MT == 4 && NT == 4 && WCH == 2 && a.phase && a.w2) {
       // Phase conv + proto.cv3 in one epilogue.  The 128 ch x 128 px tile Z = SiLU(phase conv) goes to LDS as fp16
       // [pixel][128 ch] (16-byte chunk c of pixel p in slot c ^ (p & 15): conflict-free for the writes below and for the
@@ -729,6 +809,9 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   if (a.ksize == 2 && a.phase && ((tile == TILE_128x128 && a.convt_co % 128) || (tile != TILE_128x128 && tile != TILE_64x128)))
     return -1;   // a channel tile must lie inside one phase
   if (a.w2 && a.phase && !(a.ksize == 2 && tile == TILE_128x128 && a.convt_co == 128 && a.cout2 == 32 && a.bias2)) return -1;
+  if (a.dec_preds && !(a.ksize == 1 && a.out_f32 && tile == TILE_128x128 && a.Cout == 64 + a.dec_nc + a.dec_nm && a.Cout <= 128 &&
+                       (a.Cout + 4 + a.dec_nc + a.dec_nm) * 64 * 4 <= 65536 && !a.res && a.convt_co == 0))
+    return -1;
   // conv + following 1x1 in one launch: one channel tile holding every channel, square 1x1, fp16 out
   if (a.w2 && !a.phase &&
       !(a.ksize != 2 && a.bias2 && !a.out_f32 && a.convt_co == 0 && !a.tmode && a.cout2 == a.Cout &&

@@ -57,6 +57,7 @@ struct Op {
   double bytes = 0;       // algorithmic activation bytes per image (in + out + residual)
   double wbytes = 0;      // weight bytes (read once per launch)
   int tile = -1;
+  int decode = 0;         // head output conv that also decodes its rows into the prediction tensor (no OP_DECODE launch)
   // stream lanes (plan_lanes): lane 0 is the caller's stream, lanes >= 1 are engine-owned side streams
   int lane = 0;
   std::vector<int> wait_ops;   // ops on OTHER lanes whose completion event this op's stream waits for before the launch
@@ -113,6 +114,9 @@ struct m355_engine {
   // sub-batches: the leading large-map ops run over `sub_batch` images at a time, so that a tensor (26-52 MB instead of
   // 105-210 MB at batch 32) is still in the 256 MiB Infinity Cache when its consumer reads it
   int sub_batch = 0, sub_ops = 0;
+  // head output convs decode in their epilogue (all three levels, else none); the raw maps are then written only on request
+  bool decode_fused = false;
+  int keep_raw = 1;
   // profiling: HIP events around every op launch, recorded on the caller's stream (single lane while profiling)
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;   // 2 events per op per recorded forward
@@ -506,6 +510,24 @@ void fuse_conv_cv1(m355_engine* e) {
   }
 }
 
+// The three head output convs (block-diagonal 1x1, fp32 rows of 64 + nc + nm) decode their own rows when a 128-channel
+// tile holds a whole row and 64 raw + 64 decoded rows fit the LDS stages.  All three levels or none: OP_DECODE is then
+// not launched at all.
+void fuse_decode(m355_engine* e) {
+  // measured at batch 32: 179 us for the three launches against 93 + 39 us separately, -1 % end to end (two serial 64-pixel
+  // passes with four barriers each behind every tile): opt-in
+  if (!getenv("M355_DECFUSE")) return;
+  const int wi = 64 + e->nc + e->nm, wo = 4 + e->nc + e->nm;
+  if (wi > 128 || (wi + wo) * 64 * 4 > 65536) return;
+  int n = 0;
+  for (Op& op : e->ops)
+    if (op.kind == OP_CONV && op.out_ext == 1 && e->phys[op.conv].diag && e->phys[op.conv].cout == wi && op.raw_off == 0) ++n;
+  if (n != 3) return;
+  for (Op& op : e->ops)
+    if (op.kind == OP_CONV && op.out_ext == 1) op.decode = 1;
+  e->decode_fused = true;
+}
+
 // Producers of op i in the current op order: earlier ops that write a tensor it reads; the decode reads the raw head map.
 std::vector<int> op_producers(const m355_engine* e, int i) {
   const Op& op = e->ops[i];
@@ -674,6 +696,7 @@ void annotate_ops(m355_engine* e) {
         }
         op.tile = conv_pick_tile(cout_v, e->desc.max_batch * Ho * Wo);
         if (k == 1 && op.tile == TILE_128x128 && getenv("M355_K1_TILE")) op.tile = atoi(getenv("M355_K1_TILE"));
+        if (op.decode) op.tile = TILE_128x128;   // the whole 64 + nc + nm row of a pixel in one channel tile
         bool wide = false;
         {
           ConvArgs probe{};
@@ -700,6 +723,9 @@ void annotate_ops(m355_engine* e) {
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_halo<%s>", cout_v > 64 ? "128ch" : "64ch");
         else
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d>", tile_names[op.tile], k);
+        if (op.decode) {
+          snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<128x128,k1+decode>");
+        }
         if (op.kind == OP_CONV && p.l3 >= 0) {   // + the 1x1 conv in the epilogue
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d+1x1>", tile_names[op.tile], k);
           snprintf(op.layer, sizeof(op.layer), "%s+%s", e->convs[p.logical[0]].name, e->convs[p.l3].name);
@@ -707,6 +733,8 @@ void annotate_ops(m355_engine* e) {
         }
         op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)Ho * Wo * cout_v * (op.out_ext == 1 ? 4 : 2) +
                    (op.res.t >= 0 ? (double)Ho * Wo * cout_v * 2 : 0.0);
+        if (op.decode)       // writes prediction rows (4 + nc + nm floats) instead of (or besides) the raw rows
+          op.bytes = (double)ti.H * ti.W * p.cin * 2 + (double)Ho * Wo * (4 + e->nc + e->nm) * 4 + (e->keep_raw ? (double)Ho * Wo * cout_v * 4 : 0.0);
         if (op.in2.t >= 0)   // the read-through part is a quarter-size tensor
           op.bytes -= (double)ti.H * ti.W * op.in2.c * 2 * 0.75;
         op.wbytes = (double)p.cout_pad * p.Kpad * 2;
@@ -793,6 +821,7 @@ int m355_create(const m355_model_desc* desc, m355_engine** out) {
   e->desc = *desc;
   int rc = build_graph(e);
   if (rc == 0) fuse_conv_cv1(e);
+  if (rc == 0) fuse_decode(e);
   if (rc == 0) rc = plan_lanes(e);
   if (rc == 0) plan_sub_batches(e);
   if (rc == 0) rc = alloc_all(e);
@@ -1053,6 +1082,10 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           if (a.x2) a.x2 += b0 * a.x2_bstride;
           if (a.res) a.res += b0 * a.r_bstride;
         }
+        if (op.decode) {
+          a.dec_preds = d_preds; a.dec_A = e->A; a.dec_level_off = op.level_off; a.dec_nc = e->nc; a.dec_nm = e->nm;
+          a.dec_keep_raw = e->keep_raw; a.dec_stride = (float)(e->desc.in_h / a.Ho);
+        }
         if (op.kind == OP_CONV && e->phys[op.conv].l3 >= 0) {   // following 1x1 conv in this launch's epilogue
           const PhysConv& pf = e->phys[op.conv];
           a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2;
@@ -1076,6 +1109,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         break;
       }
       case OP_DECODE:
+        if (e->decode_fused) break;   // the three head output convs wrote the prediction rows
         rc = launch_head_decode(e->raw, Bq, e->desc.in_h, e->desc.in_w, e->nc, e->nm, d_preds, s);
         break;
     }
@@ -1154,8 +1188,16 @@ int m355_get_raw_head(m355_engine* e, const float** d_raw, int* width) {
   return M355_OK;
 }
 
+int m355_set_keep_raw(m355_engine* e, int keep) {
+  if (!e) return M355_ERR_INVALID;
+  e->keep_raw = keep != 0;
+  return M355_OK;
+}
+
 int m355_copy_raw_head(m355_engine* e, int B, float* d_out, void* stream) {
   if (!e) return M355_ERR_INVALID;
+  if (e->decode_fused && !e->keep_raw)
+    return e->fail(M355_ERR_STATE, "the raw head maps are not written (m355_set_keep_raw(e, 1) before the forward)");
   if (!d_out || B < 1 || B > e->desc.max_batch) return e->fail(M355_ERR_INVALID, "bad argument");
   const size_t n = (size_t)B * e->A * (64 + e->nc + e->nm) * sizeof(float);
   HIP_TRY(e, hipMemcpyAsync(d_out, e->raw, n, hipMemcpyDeviceToDevice, (hipStream_t)stream));

@@ -28,7 +28,9 @@ class SegEngine:
     """One engine per device.  Not thread-safe (one handle, one caller)."""
 
     def __init__(self, scale: str = "s", nc: int = 1, imgsz: Tuple[int, int] = (640, 640),
-                 max_batch: int = 32, device: int = 0):
+                 max_batch: int = 32, device: int = 0, keep_raw: bool = True):
+        """keep_raw: also write the raw head maps (`raw_head()`); the predict path and bench.py pass False — the head
+        output convs decode their rows in their own epilogue and the raw maps are a parity / debugging output."""
         if not torch.cuda.is_available():
             raise RuntimeError("libmi355yolo needs a gfx950 GPU; there is no CPU fallback")
         self.device = torch.device("cuda", device)
@@ -38,6 +40,7 @@ class SegEngine:
             torch.cuda.init()
             desc = ModelDesc(ord(scale), nc, imgsz[0], imgsz[1], max_batch)
             check(lib.m355_create(C.byref(desc), C.byref(self._h)))
+            check(lib.m355_set_keep_raw(self._h, int(keep_raw)), self._h)
         self.num_anchors = lib.m355_num_anchors(self._h)
         self.pred_width = lib.m355_pred_width(self._h)
         ph, pw = C.c_int(), C.c_int()

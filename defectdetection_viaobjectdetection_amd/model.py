@@ -141,7 +141,7 @@ class YOLO:
         if eng is None or eng.max_batch < batch:
             if eng is not None:
                 eng.close()
-            eng = SegEngine(self.scale, self.nc, shape, max_batch=max(batch, 1), device=device)
+            eng = SegEngine(self.scale, self.nc, shape, max_batch=max(batch, 1), device=device, keep_raw=False)
             eng.load_state_dict(self.state_dict)
             self._engines[key] = eng
         return eng

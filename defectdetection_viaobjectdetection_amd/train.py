@@ -98,7 +98,7 @@ class Validator:
         self.ds, self.nc, self.device = dataset, nc, device
         self.conf, self.iou, self.max_det = conf, iou, max_det
         self.batch = max(1, min(batch, len(dataset)))
-        self.engine = SegEngine(scale, nc, dataset.imgsz, max_batch=self.batch, device=device)
+        self.engine = SegEngine(scale, nc, dataset.imgsz, max_batch=self.batch, device=device, keep_raw=False)
         self._gt: Dict[int, Tuple[np.ndarray, np.ndarray, torch.Tensor]] = {}
 
     def _ground_truth(self, i: int):

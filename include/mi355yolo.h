@@ -111,6 +111,9 @@ int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts);        
 int m355_get_raw_head(m355_engine* e, const float** d_raw, int* width);
 /* Asynchronous device-to-device copy of the first `batch` images of the raw head maps into d_out. */
 int m355_copy_raw_head(m355_engine* e, int batch, float* d_out, void* stream);
+/* With the decode fused into the head output convs (experiment switch M355_DECFUSE at m355_create time) the raw maps
+ * are written besides the predictions only while keep != 0 (the default of a new engine); without it they always are. */
+int m355_set_keep_raw(m355_engine* e, int keep);
 
 /* Post-processing: batched NMS + mask assembly.
  *   d_dets   float32 (B, max_det, 6+32)  rows [x1,y1,x2,y2,conf,cls,coefs] in letterboxed pixels,

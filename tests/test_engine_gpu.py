@@ -322,3 +322,39 @@ def test_sub_batched_leading_ops_are_bit_identical(cuda_device):
         eng.close()
     for a, b in zip(outs[0], outs[1]):
         assert torch.equal(a, b)
+
+
+def test_decode_in_the_head_epilogue_is_bit_identical(cuda_device):
+    """M355_DECFUSE=1 (an experiment, measured slower, off by default): the three head output convs decode their rows
+    themselves (DFL expectation, dist2bbox, sigmoid, coefficient copy in the conv epilogue); the default writes the raw
+    maps and launches head_decode_kernel.  Same arithmetic on the same
+    fp32 rows: identical predictions, with and without the raw maps, and identical raw maps when they are kept.
+    Partial pixel tiles: 7 images of 608 x 640 (76 x 80, 38 x 40 and 19 x 20 maps)."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(7, seed=51)[:, :608, :].copy()).to(cuda_device)
+    outs = {}
+    for mode in ("fused", "fused_keep_raw", "separate"):
+        if mode != "separate":
+            os.environ["M355_DECFUSE"] = "1"
+        try:
+            eng = SegEngine("s", 1, (608, 640), max_batch=7, keep_raw=(mode != "fused"))
+        finally:
+            os.environ.pop("M355_DECFUSE", None)
+        kinds = [o["kernel"] for o in eng.op_infos()]
+        assert sum("+decode" in k for k in kinds) == (0 if mode == "separate" else 3)
+        assert ("head_decode" in kinds) == True   # the op stays in the list; it launches nothing when the convs decode
+        eng.load_state_dict(sd)
+        p, q = eng.forward(imgs)
+        raw = eng.raw_head(7) if mode != "fused" else None
+        torch.cuda.synchronize()
+        outs[mode] = (p.clone(), q.clone(), None if raw is None else raw.clone())
+        if mode == "fused":
+            with pytest.raises(RuntimeError):
+                eng.raw_head(7)
+        eng.close()
+    assert torch.equal(outs["fused"][0], outs["separate"][0]) and torch.equal(outs["fused_keep_raw"][0], outs["separate"][0])
+    assert torch.equal(outs["fused"][1], outs["separate"][1])
+    assert torch.equal(outs["fused_keep_raw"][2], outs["separate"][2])
