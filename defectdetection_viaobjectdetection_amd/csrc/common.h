@@ -92,7 +92,8 @@ bool conv3x3_slab_ok(const ConvArgs& a);
 int launch_conv3x3_slab(const ConvArgs& a, hipStream_t s);
 // D-FINE decoder ops (dfine_kernels.hip)
 int launch_msda(const float* value, const float* loc, const float* attn, float* out, int B, int S, int H, int D, int Q, int P,
-                int L, const int* shapes_hw, const int* points_per_level, int discrete, hipStream_t s);
+                int L, const int* shapes_hw, const int* points_per_level, int discrete, hipStream_t s,
+                const float* ref = nullptr, float offset_scale = 0.f);
 int launch_dfine_decode(const float* dist, const float* project, const float* ref, float* boxes, long n, int nbins1,
                         float reg_scale, int clamp01, hipStream_t s);
 // the same pipeline as a template over (channel block, tile height): conv3x3_lean.hip; which 0 = by shape

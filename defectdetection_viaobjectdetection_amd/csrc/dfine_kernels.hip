@@ -19,6 +19,11 @@ struct MsdaArgs {
   int B, S, H, Q, P, L;
   int lh[8], lw[8], lstart[8], pend[8];   // level height / width / first pixel / one past its last point
   int discrete;
+  // module mode (DFineMultiscaleDeformableAttention.forward with 4-d reference points, modeling_d_fine.py:268-296):
+  // loc holds the RAW sampling offsets and attn the RAW attention logits of the two linear layers; the kernel forms
+  //   location = ref.xy + offset * (1 / points of the level) * ref.wh * offset_scale,   weight = softmax over the P points
+  const float* ref;     // (B, Q, 4) cx, cy, w, h; nullptr: loc / attn are final
+  float offset_scale;
 };
 
 __global__ __launch_bounds__(256) void msda_kernel(const MsdaArgs a) {
@@ -85,6 +90,20 @@ __global__ __launch_bounds__(256) void msda_wave_kernel(const MsdaArgs a) {
   if (triple >= (long)a.B * a.Q * a.H) return;   // whole waves leave together
   const int h = (int)(triple % a.H);
   const int b = (int)(triple / a.H / a.Q);
+  // module mode: softmax of the P raw logits.  Point p sits on lanes 4p .. 4p+3, so the xor-shuffles 4 .. 32 reduce over
+  // the points inside each corner class; idle lanes carry -inf / 0.
+  float soft = 0.f;
+  if (a.ref) {
+    const float z = lane < 4 * a.P ? a.attn[triple * a.P + (lane >> 2)] : -INFINITY;
+    float m = z;
+#pragma unroll
+    for (int k = 4; k < 64; k <<= 1) m = fmaxf(m, __shfl_xor(m, k, 64));
+    const float e = lane < 4 * a.P ? __expf(z - m) : 0.f;
+    float sum = e;
+#pragma unroll
+    for (int k = 4; k < 64; k <<= 1) sum += __shfl_xor(sum, k, 64);
+    soft = e / sum;
+  }
   int my_off = 0;       // pixel index (level start included) of this lane's corner, 0 when the corner contributes nothing
   float my_wt = 0.f;
   if (lane < 4 * a.P) {
@@ -93,7 +112,13 @@ __global__ __launch_bounds__(256) void msda_wave_kernel(const MsdaArgs a) {
     while (p >= a.pend[l]) ++l;
     const int W = a.lw[l], Hh = a.lh[l];
     const float* lp = a.loc + (triple * a.P + p) * 2;
-    const float x = lp[0], y = lp[1], aw = a.attn[triple * a.P + p];
+    float x = lp[0], y = lp[1], aw = a.ref ? soft : a.attn[triple * a.P + p];
+    if (a.ref) {
+      const float* rp = a.ref + (triple / a.H) * 4;
+      const float nscale = 1.0f / (float)(a.pend[l] - (l ? a.pend[l - 1] : 0));
+      x = rp[0] + x * nscale * rp[2] * a.offset_scale;   // reference op order: offsets * scale * wh * offset_scale
+      y = rp[1] + y * nscale * rp[3] * a.offset_scale;
+    }
     if (a.discrete) {
       long xi = (long)(x * (float)W + 0.5f), yi = (long)(y * (float)Hh + 0.5f);
       xi = xi < 0 ? 0 : (xi > W - 1 ? W - 1 : xi);
@@ -170,12 +195,15 @@ __global__ void dfine_decode_kernel(const float* dist, const float* project, con
 }  // namespace
 
 int launch_msda(const float* value, const float* loc, const float* attn, float* out, int B, int S, int H, int D, int Q,
-                int P, int L, const int* shapes_hw, const int* points_per_level, int discrete, hipStream_t s) {
+                int P, int L, const int* shapes_hw, const int* points_per_level, int discrete, hipStream_t s, const float* ref,
+                float offset_scale) {
   if (!value || !loc || !attn || !out || !shapes_hw || !points_per_level) return -1;
+  if (ref && (P > 16 || discrete)) return -1;   // module mode lives in the wave kernel (bilinear, at most 16 points)
   if (D != 32 || L < 1 || L > 8 || P < 1 || P > 32 || B < 1 || Q < 1 || H < 1) return -1;
   MsdaArgs a{};
   a.value = value; a.loc = loc; a.attn = attn; a.out = out;
   a.B = B; a.S = S; a.H = H; a.Q = Q; a.P = P; a.L = L; a.discrete = discrete;
+  a.ref = ref; a.offset_scale = offset_scale;
   int start = 0, pend = 0;
   for (int l = 0; l < L; ++l) {
     a.lh[l] = shapes_hw[2 * l]; a.lw[l] = shapes_hw[2 * l + 1];

@@ -1546,6 +1546,18 @@ int m355_msda_forward(const float* d_value, int32_t B, int32_t S, int32_t heads,
     return set_err(M355_ERR_INVALID, "msda: head_dim must be 32, 1..8 levels tiling S, 1..32 points tiling P");
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "msda launch failed: " + std::to_string(rc));
 }
+int m355_msda_module_forward(const float* d_value, int32_t B, int32_t S, int32_t heads, int32_t head_dim, const int32_t* shapes_hw,
+                             int32_t num_levels, const float* d_ref, const float* d_offsets, const float* d_logits,
+                             const int32_t* points_per_level, int32_t Q, int32_t P, float offset_scale, float* d_out,
+                             void* stream) {
+  if (!d_value || !d_ref || !d_offsets || !d_logits || !d_out || !shapes_hw || !points_per_level)
+    return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = m355::launch_msda(d_value, d_offsets, d_logits, d_out, B, S, heads, head_dim, Q, P, num_levels, shapes_hw,
+                                   points_per_level, 0, (hipStream_t)stream, d_ref, offset_scale);
+  if (rc == -1)
+    return set_err(M355_ERR_INVALID, "msda module: head_dim must be 32, 1..8 levels tiling S, 1..16 points tiling P");
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "msda launch failed: " + std::to_string(rc));
+}
 int m355_dfine_decode(const float* d_dist, const float* d_project, const float* d_ref, float* d_boxes, int64_t n,
                       int32_t num_bins_plus1, float reg_scale, int32_t clamp01, void* stream) {
   const int rc = m355::launch_dfine_decode(d_dist, d_project, d_ref, d_boxes, (long)n, num_bins_plus1, reg_scale, clamp01,

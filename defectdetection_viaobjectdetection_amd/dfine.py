@@ -56,6 +56,36 @@ def multi_scale_deformable_attention_v2(value: torch.Tensor, value_spatial_shape
     return out
 
 
+def deformable_attention(hidden_states: torch.Tensor, reference_points: torch.Tensor, encoder_hidden_states: torch.Tensor,
+                         spatial_shapes_list, sampling_offsets: torch.nn.Linear, attention_weights: torch.nn.Linear,
+                         num_points_list: List[int], n_heads: int, offset_scale: float) -> torch.Tensor:
+    """DFineMultiscaleDeformableAttention.forward (modeling_d_fine.py:247-311) for 4-d reference points and method
+    "default": the two linear layers run as torch GEMMs, everything behind them (softmax over the points, sampling
+    locations from the reference boxes, bilinear gather-weighted-sum) is ONE kernel.
+    hidden_states (B, Q, d); reference_points (B, Q, 1, 4) or (B, Q, 4); encoder_hidden_states (B, S, d) -> (B, Q, d)."""
+    B, Q, d = hidden_states.shape
+    S = encoder_hidden_states.shape[1]
+    D = d // n_heads
+    P = sum(num_points_list)
+    shapes = [(int(h), int(w)) for h, w in spatial_shapes_list]
+    if sum(h * w for h, w in shapes) != S:
+        raise ValueError("Make sure to align the spatial shapes with the sequence length of the encoder hidden states")
+    ref = reference_points.reshape(B, Q, -1)
+    if ref.shape[-1] != 4:
+        raise ValueError(f"Last dim of reference_points must be 4 for the fused form, but get {ref.shape[-1]} instead.")
+    value = _f32c(encoder_hidden_states, "encoder_hidden_states")          # (B, S, heads, D) is a view of (B, S, d)
+    off = _f32c(sampling_offsets(hidden_states), "sampling offsets")       # (B, Q, heads * P * 2)
+    logit = _f32c(attention_weights(hidden_states), "attention logits")    # (B, Q, heads * P)
+    ref = _f32c(ref, "reference_points")
+    out = torch.empty((B, Q, d), dtype=torch.float32, device=value.device)
+    sh = (C.c_int32 * (2 * len(shapes)))(*[v for hw in shapes for v in hw])
+    pp = (C.c_int32 * len(shapes))(*[int(n) for n in num_points_list])
+    check(lib.m355_msda_module_forward(C.c_void_p(value.data_ptr()), B, S, n_heads, D, sh, len(shapes), C.c_void_p(ref.data_ptr()),
+                                       C.c_void_p(off.data_ptr()), C.c_void_p(logit.data_ptr()), pp, Q, P, float(offset_scale),
+                                       C.c_void_p(out.data_ptr()), _stream()))
+    return out
+
+
 def weighting_function(max_num_bins: int, up: torch.Tensor, reg_scale) -> torch.Tensor:
     """W(n), max_num_bins + 1 values (modeling_d_fine.py:1091-1112); a few dozen scalars: computed with torch ops on
     the device `up` lives on, in the reference's order of operations."""

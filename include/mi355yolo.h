@@ -253,6 +253,15 @@ int m355_augment(const void* d_cache, const m355_aug_params* d_params, void* d_o
 int m355_msda_forward(const float* d_value, int32_t B, int32_t S, int32_t heads, int32_t head_dim, const int32_t* shapes_hw,
                       int32_t num_levels, const float* d_loc, const float* d_attn, const int32_t* points_per_level,
                       int32_t Q, int32_t P, int32_t discrete, float* d_out, void* stream);
+/* m355_msda_module_forward = the part of DFineMultiscaleDeformableAttention.forward (modeling_d_fine.py:268-311) behind its
+ * two linear layers, for 4-d reference points and method "default": softmax of the attention logits over the P points,
+ * sampling location = ref.xy + offset * (1 / points of the level) * ref.wh * offset_scale, then the core above.
+ *   ref (B, Q, 4) cx, cy, w, h; offsets (B, Q, heads, P, 2) and logits (B, Q, heads, P): raw outputs of
+ *   `sampling_offsets` / `attention_weights`; P <= 16; out (B, Q, heads * head_dim). */
+int m355_msda_module_forward(const float* d_value, int32_t B, int32_t S, int32_t heads, int32_t head_dim, const int32_t* shapes_hw,
+                             int32_t num_levels, const float* d_ref, const float* d_offsets, const float* d_logits,
+                             const int32_t* points_per_level, int32_t Q, int32_t P, float offset_scale, float* d_out,
+                             void* stream);
 /* m355_dfine_decode = DFineIntegral.forward (modeling_d_fine.py:756-778) + distance2bbox (:1115-1137) [+ .clamp(0, 1)],
  * temporal_dfine.py:180-181.  dist (n, 4 * num_bins_plus1) fp32 logits; project (num_bins_plus1) fp32 = W(n) from
  * weighting_function (:1091-1112, host side: dfine.py); ref (n, 4) fp32 (cx, cy, w, h); boxes (n, 4) fp32 (cx, cy, w, h). */

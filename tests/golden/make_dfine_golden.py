@@ -28,6 +28,22 @@ for tag, pts in (("a", [4, 4, 4]), ("b", [3, 6, 3])):
         out[f"msda_{tag}_{method}"] = y.numpy()
     out[f"loc_{tag}"], out[f"attn_{tag}"], out[f"pts_{tag}"] = loc.numpy(), attn.numpy(), np.array(pts, np.int32)
 out["value"] = value.numpy()
+# the attention module itself (random init, 4-d reference points): inputs, the two linear layers' outputs, the result
+torch.manual_seed(1)
+cfgm = DFineConfig()
+mod = M.DFineMultiscaleDeformableAttention(cfgm).eval()
+hidden = torch.randn(B, Q, cfgm.d_model, generator=g)
+enc = value.reshape(B, S, H * D)
+refp = torch.rand(B, Q, 1, 4, generator=g) * torch.tensor([1.0, 1.0, 0.4, 0.4]) + torch.tensor([0.0, 0.0, 0.02, 0.02])
+with torch.no_grad():
+    ym, _ = mod(hidden, reference_points=refp, encoder_hidden_states=enc, spatial_shapes=torch.tensor(shapes),
+                spatial_shapes_list=shapes)
+    out["mod_offsets"] = mod.sampling_offsets(hidden).reshape(B, Q, H, 12, 2).numpy()
+    out["mod_logits"] = mod.attention_weights(hidden).reshape(B, Q, H, 12).numpy()
+out["mod_hidden"], out["mod_ref"], out["mod_out"] = hidden.numpy(), refp.reshape(B, Q, 4).numpy(), ym.numpy()
+out["mod_w_off"], out["mod_b_off"] = mod.sampling_offsets.weight.detach().numpy(), mod.sampling_offsets.bias.detach().numpy()
+out["mod_w_att"], out["mod_b_att"] = mod.attention_weights.weight.detach().numpy(), mod.attention_weights.bias.detach().numpy()
+out["mod_offset_scale"] = np.array(mod.offset_scale, np.float32)
 up, reg = torch.tensor([0.5]), torch.tensor([4.0])
 proj = M.weighting_function(32, up, reg)
 out["project"] = proj.numpy()

@@ -97,6 +97,36 @@ def test_msda_full_size_properties(cuda_device):
     assert np.abs(y1[:1].cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
 
 
+def test_attention_module_golden(cuda_device):
+    """dfine.deformable_attention = the transformers module: same weights, same inputs (the two linear layers run as torch
+    GEMMs on the GPU; softmax, sampling locations and the gather are one kernel)."""
+    from defectdetection_viaobjectdetection_amd import dfine
+    B, S, H, D = G["value"].shape
+    lin_o = torch.nn.Linear(256, 192).to(cuda_device)
+    lin_a = torch.nn.Linear(256, 96).to(cuda_device)
+    with torch.no_grad():
+        lin_o.weight.copy_(_t(G["mod_w_off"], cuda_device)); lin_o.bias.copy_(_t(G["mod_b_off"], cuda_device))
+        lin_a.weight.copy_(_t(G["mod_w_att"], cuda_device)); lin_a.bias.copy_(_t(G["mod_b_att"], cuda_device))
+        y = dfine.deformable_attention(_t(G["mod_hidden"], cuda_device), _t(G["mod_ref"], cuda_device)[:, :, None],
+                                       _t(G["value"], cuda_device).reshape(B, S, H * D), SHAPES, lin_o, lin_a, [4, 4, 4], 8,
+                                       float(G["mod_offset_scale"]))
+    ref = G["mod_out"]
+    # the GEMMs run in a different order on the GPU: a few 1e-6 on the logits / offsets, amplified by the map's gradients
+    assert np.abs(y.cpu().numpy() - ref).max() <= 5e-5 * max(1.0, np.abs(ref).max())
+    # the kernel alone, fed with the reference's own linear outputs: tight
+    import ctypes as C
+    from defectdetection_viaobjectdetection_amd._capi import check, lib
+    Q = G["mod_ref"].shape[1]
+    val, rf = _t(G["value"], cuda_device), _t(G["mod_ref"], cuda_device)
+    off, lg = _t(G["mod_offsets"], cuda_device), _t(G["mod_logits"], cuda_device)
+    out = torch.empty((B, Q, H * D), device=cuda_device)
+    sh = (C.c_int32 * 6)(*[v for hw in SHAPES for v in hw]); pp = (C.c_int32 * 3)(4, 4, 4)
+    P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    check(lib.m355_msda_module_forward(P(val), B, S, H, D, sh, 3, P(rf), P(off), P(lg), pp, Q, 12, float(G["mod_offset_scale"]),
+                                       P(out), C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    assert np.abs(out.cpu().numpy() - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
 def test_decode_golden(cuda_device):
     from defectdetection_viaobjectdetection_amd import dfine
     proj = dfine.weighting_function(32, torch.tensor([0.5], device=cuda_device), 4.0)

@@ -43,3 +43,12 @@ def test_integral_and_distance2bbox_match_transformers():
     refc = G["boxes_clamped"]
     assert np.array_equal(np.isnan(bc), np.isnan(refc))
     np.testing.assert_allclose(bc[~np.isnan(refc)], refc[~np.isnan(refc)], rtol=1e-6, atol=1e-7)
+
+
+def test_attention_module_matches_transformers():
+    """DFineMultiscaleDeformableAttention.forward (random init, 4-d reference points) vs the restatement fed with the
+    module's own linear-layer outputs."""
+    y = orc.deformable_attention_module(G["value"], SHAPES, G["mod_ref"], G["mod_offsets"], G["mod_logits"], [4, 4, 4],
+                                        float(G["mod_offset_scale"]))
+    ref = G["mod_out"]
+    assert y.shape == ref.shape and np.abs(y - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())

@@ -35,6 +35,21 @@ try:
     out["max_abs_diff_vs_torch_rocm"] = float((ref - mine).abs().max())
 except Exception as ex:  # transformers missing on the box
     out["torch_rocm_us"] = None; out["note"] = repr(ex)
+# the whole attention module (two linear layers + softmax + locations + core), random-init weights
+try:
+    from transformers.models.d_fine.configuration_d_fine import DFineConfig
+    mod = M.DFineMultiscaleDeformableAttention(DFineConfig()).cuda().eval()
+    hidden = torch.randn(B, Q, 256, generator=g).cuda()
+    refp = (torch.rand(B, Q, 1, 4, generator=g) * torch.tensor([1.0, 1.0, 0.4, 0.4]) + torch.tensor([0.0, 0.0, 0.02, 0.02])).cuda()
+    enc = value.reshape(B, S, H * D)
+    with torch.no_grad():
+        f_ref = lambda: mod(hidden, reference_points=refp, encoder_hidden_states=enc, spatial_shapes=torch.tensor(shapes), spatial_shapes_list=shapes)[0]  # noqa: E731
+        f_hip = lambda: dfine.deformable_attention(hidden, refp, enc, shapes, mod.sampling_offsets, mod.attention_weights, pts, 8, mod.offset_scale)  # noqa: E731
+        out["module_torch_rocm_us"] = round(timeit(f_ref, 20), 1)
+        out["module_hip_us"] = round(timeit(f_hip, 50), 1)
+        out["module_max_abs_diff"] = float((f_ref() - f_hip()).abs().max())
+except Exception as ex:
+    out["module_note"] = repr(ex)
 import dfine_oracle as orc
 v1, l1, a1 = value[:1].cpu().numpy(), loc[:1].cpu().numpy(), attn[:1].cpu().numpy()
 t0 = time.perf_counter(); orc.multi_scale_deformable_attention_v2(v1, shapes, l1, a1, pts); el = time.perf_counter() - t0
