@@ -280,6 +280,7 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
         # 7 images of 608 x 640: the 76 x 80 map of model.3 gives 332.5 pixel tiles (a partial one), enough for the 128-channel tile
         imgs = torch.from_numpy(synthetic_bscans(7, seed=31)[:, :608, :].copy()).to(cuda_device)
         outs = []
+        saved = os.environ.pop("M355_NO_CVFUSE", None)
         for fuse in (True, False):
             if not fuse:
                 os.environ["M355_NO_CVFUSE"] = "1"
@@ -294,6 +295,8 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
             torch.cuda.synchronize()
             outs.append((p.clone(), q.clone()))
             eng.close()
+        if saved is not None:
+            os.environ["M355_NO_CVFUSE"] = saved
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), scale
 
 
