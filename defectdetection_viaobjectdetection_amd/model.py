@@ -98,10 +98,11 @@ class YOLO:
         self._drop_engines()
 
     def _load_checkpoint(self, path: str) -> None:
+        import pickle
         ck = None
         try:
             ck = torch.load(path, map_location="cpu", weights_only=True)
-        except Exception:  # noqa: BLE001 -- not one of ours (or not loadable without class definitions)
+        except pickle.UnpicklingError:  # torch's weights-only loader met a class: not one of ours, maybe upstream's
             ck = None
         if not isinstance(ck, dict) or ck.get("format") != CKPT_FORMAT:
             # a checkpoint written by upstream Ultralytics: recover the tensors without its classes (upstream_ckpt.py)

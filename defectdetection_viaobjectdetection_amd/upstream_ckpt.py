@@ -3,8 +3,9 @@
 The reference loads weights by path (`YOLO(model_path)`, /root/reference/BscanBased/yolo8_seg_predict.py:5-6); such a
 `.pt` is a pickle of `{'model': <SegmentationModel nn.Module>, 'ema': ..., 'train_args': {...}, ...}` whose class
 definitions live in the un-vendored package.  Nothing of those classes is needed to recover the weights: this module
-unpickles with an ALLOW-LISTED Unpickler (torch / collections / numpy / builtins types are real; every other class
-becomes an inert placeholder that only stores its state), then walks the placeholder graph along nn.Module's own
+unpickles with an EXACT allow-list (torch's tensor rebuild functions, storages, dtypes, a few containers and numpy
+scalars are real; classes of ultralytics / torch.nn / pathlib / argparse become inert placeholders that only store
+their state; every other global, and every dotted attribute path, raises UnpicklingError), then walks the placeholder graph along nn.Module's own
 `_modules / _parameters / _buffers` dictionaries and rebuilds the `state_dict()` the model would have produced.  The
 graph (YOLOv8{n,s,m,l,x}-seg) is recognised from tensor names and shapes; anything else is rejected with a message.
 No code from the pickle is executed beyond torch's tensor rebuild functions.
@@ -17,14 +18,30 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-_ALLOWED_PREFIXES = ("torch", "collections", "numpy", "builtins", "_codecs", "copyreg", "__builtin__", "pathlib",
-                     "types", "typing", "datetime", "argparse")
-_FORBIDDEN_BUILTINS = {"eval", "exec", "compile", "open", "__import__", "getattr", "setattr", "delattr", "input", "vars",
-                       "globals", "locals", "breakpoint"}
+# Exact (module, name) pairs that resolve to REAL objects.  Everything a YOLO checkpoint needs to rebuild its tensors and
+# plain containers, and nothing that can call back into Python: no attribute paths (pickle protocol 4 resolves dotted
+# names), no `torch.serialization`, `torch.storage._load_from_bytes`, `types`, `functools`, `operator`, `os`.
+_TORCH_STORAGES = ("FloatStorage", "HalfStorage", "BFloat16Storage", "DoubleStorage", "LongStorage", "IntStorage",
+                   "ShortStorage", "CharStorage", "ByteStorage", "BoolStorage", "UntypedStorage")
+_REAL = {("collections", "OrderedDict"), ("collections", "defaultdict"),
+         ("torch._utils", "_rebuild_tensor_v2"), ("torch._utils", "_rebuild_tensor"),
+         ("torch._utils", "_rebuild_parameter"), ("torch", "Size"), ("torch", "device"),
+         ("torch.storage", "UntypedStorage"),
+         ("_codecs", "encode"),
+         ("numpy", "dtype"), ("numpy", "ndarray"),
+         ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+         ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct")}
+_REAL |= {("torch", n) for n in _TORCH_STORAGES}
+_REAL_BUILTINS = {"set", "frozenset", "slice", "dict", "list", "tuple", "int", "float", "bool", "str", "bytes",
+                  "bytearray", "complex", "range", "object"}
+# Module roots whose classes are expected in an upstream checkpoint but are never needed as real objects: instances
+# become inert placeholders that only keep their state (nn.Module graphs, Path / Namespace values in train_args, ...).
+_PLACEHOLDER_ROOTS = {"ultralytics", "models", "utils", "yolov5", "__main__", "pathlib", "argparse", "datetime"}
+_PLACEHOLDER_EXACT = {("types", "SimpleNamespace"), ("torch", "Tensor")}
 
 
 class _Placeholder:
-    """Stands for an instance of a class that cannot be imported: keeps whatever state the pickle restores."""
+    """Stands for an instance of a class that cannot (or must not) be imported: keeps whatever state the pickle restores."""
 
     def __init__(self, *args, **kwargs):
         pass
@@ -53,21 +70,59 @@ def _placeholder_class(module: str, name: str) -> type:
     return _placeholder_types[key]
 
 
+def _safe_rebuild_from_type_v2(func, new_type, args, state):
+    """torch._tensor._rebuild_from_type_v2 without `new_type.__setstate__` / attribute injection: the tensor only."""
+    if func not in (torch._utils._rebuild_tensor_v2, torch._utils._rebuild_tensor, torch._utils._rebuild_parameter):
+        raise pickle.UnpicklingError("refusing a tensor rebuild through an unknown function")
+    return func(*args)
+
+
+def _safe_rebuild_parameter_with_state(data, requires_grad, backward_hooks, state):
+    return torch._utils._rebuild_parameter(data, requires_grad, backward_hooks)
+
+
+def _safe_reconstructor(cls, base, state):
+    """copyreg._reconstructor for protocol-0/1 pickles: only placeholder classes are ever instantiated."""
+    if isinstance(cls, type) and issubclass(cls, _Placeholder):
+        return cls()
+    raise pickle.UnpicklingError(f"refusing copyreg._reconstructor for {cls!r}")
+
+
+_SAFE_SUBSTITUTES = {("torch._tensor", "_rebuild_from_type_v2"): _safe_rebuild_from_type_v2,
+                     ("torch._utils", "_rebuild_parameter_with_state"): _safe_rebuild_parameter_with_state,
+                     ("copyreg", "_reconstructor"): _safe_reconstructor, ("copy_reg", "_reconstructor"): _safe_reconstructor}
+
+
 class _Unpickler(pickle.Unpickler):
+    """Exact allow-list.  (module, name) resolves to a real object only when listed above; names containing '.' never
+    do (protocol 4's STACK_GLOBAL would walk attributes: ('torch.serialization', 'os.system') reaches os).  Classes of
+    the expected foreign packages become placeholders; anything else is refused."""
+
     def find_class(self, module, name):
+        key = (module, name)
         root = module.split(".")[0]
-        if root in _ALLOWED_PREFIXES:
-            if root in ("builtins", "__builtin__") and name in _FORBIDDEN_BUILTINS:
-                raise pickle.UnpicklingError(f"refusing builtins.{name} in a checkpoint")
-            if root == "torch" and not module.startswith(("torch._utils", "torch.nn", "torch._tensor", "torch.storage",
-                                                           "torch.serialization", "torch.distributed", "torch.optim",
-                                                           "torch.cuda", "torch.amp")) and module != "torch":
+        if "." in name:
+            if root in _PLACEHOLDER_ROOTS:
                 return _placeholder_class(module, name)
+            raise pickle.UnpicklingError(f"refusing dotted global {module}:{name} in a checkpoint")
+        if key in _SAFE_SUBSTITUTES:
+            return _SAFE_SUBSTITUTES[key]
+        if key in _REAL:
+            import importlib
             try:
-                return super().find_class(module, name)
+                return getattr(importlib.import_module(module), name)
             except (ImportError, AttributeError):
-                return _placeholder_class(module, name)
-        return _placeholder_class(module, name)
+                raise pickle.UnpicklingError(f"{module}.{name} is allow-listed but not importable here")
+        if root in ("builtins", "__builtin__"):
+            if name in _REAL_BUILTINS:
+                import builtins
+                return getattr(builtins, name)
+            raise pickle.UnpicklingError(f"refusing builtins.{name} in a checkpoint")
+        if module == "torch" and isinstance(getattr(torch, name, None), torch.dtype):
+            return getattr(torch, name)
+        if root in _PLACEHOLDER_ROOTS or key in _PLACEHOLDER_EXACT or module.startswith("torch.nn."):
+            return _placeholder_class(module, name)
+        raise pickle.UnpicklingError(f"refusing global {module}.{name}: not on the checkpoint allow-list")
 
 
 class _PickleModule:

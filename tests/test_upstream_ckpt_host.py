@@ -2,6 +2,7 @@
 The fixture is fabricated here: the oracle's modules are pickled under upstream's module paths, which are then
 removed from sys.modules -- exactly the situation of a user's best.pt on a machine without the package.  CPU only."""
 import os
+import pickle
 import sys
 import types
 
@@ -77,5 +78,39 @@ def test_rejects_other_graphs_and_dangerous_pickles(tmp_path):
             return (eval, ("1+1",))
     p2 = str(tmp_path / "evil.pt")
     torch.save({"model": Evil()}, p2)
-    with pytest.raises(Exception):
+    with pytest.raises(pickle.UnpicklingError):
         load_upstream_checkpoint(p2)
+
+
+def _raw_pickle(module, name, arg):
+    """protocol-4 pickle: STACK_GLOBAL(module, name) called with (arg,) -- what a hostile checkpoint would carry."""
+    def s(x):
+        b = x.encode()
+        return b"\x8c" + bytes([len(b)]) + b
+    return b"\x80\x04" + s(module) + s(name) + b"\x93" + s(arg) + b"\x85R."
+
+
+@pytest.mark.parametrize("module,name", [
+    ("torch.serialization", "os.system"),                # dotted attribute path out of an allowed package (protocol 4)
+    ("torch.serialization", "os.getpid"),
+    ("types", "FunctionType"), ("types", "CodeType"),
+    ("numpy.testing._private.utils", "runstring"),       # calls exec
+    ("torch.storage", "_load_from_bytes"),               # torch.load(weights_only=False) on attacker bytes
+    ("torch.serialization", "load"), ("torch.hub", "load"), ("torch", "load"),
+    ("builtins", "eval"), ("builtins", "exec"), ("builtins", "getattr"), ("builtins", "__import__"),
+    ("os", "system"), ("posix", "system"), ("subprocess", "Popen"), ("functools", "partial"), ("operator", "attrgetter"),
+])
+def test_unpickler_refuses_everything_off_the_allow_list(module, name):
+    import io
+    from defectdetection_viaobjectdetection_amd.upstream_ckpt import _Unpickler
+    with pytest.raises(pickle.UnpicklingError):
+        out = _Unpickler(io.BytesIO(_raw_pickle(module, name, "echo pwned"))).load()
+        raise AssertionError(f"{module}.{name} resolved and returned {out!r}")
+
+
+def test_model_loader_only_falls_back_on_unpickling_errors(tmp_path):
+    with pytest.raises(Exception) as ei:
+        p = tmp_path / "garbage.pt"
+        p.write_bytes(b"not a checkpoint at all")
+        YOLO(str(p))
+    assert not isinstance(ei.value, (AttributeError, NotImplementedError))
