@@ -62,6 +62,10 @@ struct ConvArgs {
   float* dec_preds;        // (B, dec_A, 4 + nc + nm) fp32; nullptr: off
   int dec_A, dec_level_off, dec_nc, dec_nm, dec_keep_raw;
   float dec_stride;
+  // Rows of the packed weight buffer `w` and floats of `bias` the caller allocated (0: conv_cout_pad(Cout), the
+  // engine's padding).  Every launcher refuses a channel tile whose ceil(Cout / tile) * tile rows exceed it: the
+  // kernels fetch whole weight-row tiles by LDS-DMA with no per-row bound.
+  int w_rows;
 };
 
 // tile ids for launch_conv_igemm(force_tile)
@@ -80,6 +84,13 @@ int conv_pick_tile(int cout, long M);
 // rows the packed weight buffer must be padded to for a given Cout (multiple of the channel tile)
 int conv_cout_pad(int cout);
 int conv_kpad(int cin, int ksize);
+// true when a launch with channel tile `bch` stays inside the weight / bias rows the caller provided
+inline bool conv_rows_covered(const ConvArgs& a, int bch) {
+  const int need = (a.Cout + bch - 1) / bch * bch;
+  return need <= (a.w_rows > 0 ? a.w_rows : conv_cout_pad(a.Cout));
+}
+// (channel, pixel) extent of a forced tile id of m355_conv2d_fwd; false for ids no launcher implements
+bool conv_forced_tile_extent(int tile, int cout, int* bch, int* bpx);
 
 // 3x3 stride-1 halo-tile kernel (conv3x3_halo.hip)
 bool conv3x3_halo_ok(const ConvArgs& a);

@@ -191,7 +191,7 @@ bool conv3x3_c32_ok(const ConvArgs& a) {
 }
 
 int launch_conv3x3_c32(const ConvArgs& a, hipStream_t s) {
-  if (!conv3x3_c32_ok(a)) return -1;
+  if (!conv3x3_c32_ok(a) || !conv_rows_covered(a, 32)) return -1;
   const int tiles_x = (a.Wi + TS - 1) / TS, tiles_y = (a.Hi + TH - 1) / TH;
   const int B = a.M / (a.Ho * a.Wo);
   const int ntiles = B * tiles_y * tiles_x;

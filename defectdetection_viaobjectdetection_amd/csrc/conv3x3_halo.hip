@@ -343,6 +343,7 @@ int launch_halo_variant(const ConvArgs& a, hipStream_t s) {
   const int nchunks = a.Cin / 64;
   const int npatch = nchunks > 1 ? 2 : 1;
   const int B = a.M / (a.Ho * a.Wo);
+  if (!conv_rows_covered(a, BCH)) return -1;
   const int lds = npatch * PGROUPS * 8 * ROWB + ((WCH * WPX == 8) ? 4 : 2) * BCH * ROWB;
   auto k = conv3x3_halo_kernel<MT, NT, WCH, WPX>;
   if (lds > 65536) {

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(256, (Lean<BCH, TH>::BLOCKS)) void conv3x3_lean_ker
 template <int BCH, int TH>
 int launch_lean(const ConvArgs& a, hipStream_t s) {
   using L = Lean<BCH, TH>;
+  if (!conv_rows_covered(a, BCH)) return -1;
   const int tiles_x = (a.Wi + TS - 1) / TS, tiles_y = (a.Hi + TH - 1) / TH;
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;
   const int B = a.M / (a.Ho * a.Wo);

@@ -383,7 +383,7 @@ bool conv3x3_slab_ok(const ConvArgs& a) {
 }
 
 int launch_conv3x3_slab(const ConvArgs& a, hipStream_t s) {
-  if (!conv3x3_slab_ok(a)) return -1;
+  if (!conv3x3_slab_ok(a) || !conv_rows_covered(a, BCH)) return -1;
   const int R = slab_rows(a.Hi, a.Wi);
   const int slabs = (a.Hi + R - 1) / R;
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;

@@ -379,7 +379,7 @@ bool conv3x3_wide_ok(const ConvArgs& a) {
 }
 
 int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s) {
-  if (!conv3x3_wide_ok(a)) return -1;
+  if (!conv3x3_wide_ok(a) || !conv_rows_covered(a, BCH)) return -1;
   const int tiles_x = (a.Wi + TS - 1) / TS, tiles_y = (a.Hi + TH - 1) / TH;
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;
   const int B = a.M / (a.Ho * a.Wo);

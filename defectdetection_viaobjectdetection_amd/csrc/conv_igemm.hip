@@ -731,6 +731,7 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   constexpr int LDS = 2 * (BCH + BPX) * BK * 2;
   const int tiles_ch = (a.Cout + BCH - 1) / BCH;
   const int tiles_px = (a.M + BPX - 1) / BPX;
+  if (!conv_rows_covered(a, BCH)) return -1;   // the tile would fetch weight rows past the caller's buffer
   if (g_num_cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -792,6 +793,24 @@ int conv_pick_tile(int cout, long M) {
   if (cout > 64) return TILE_128x128;
   if (cout > 32) return TILE_64x128;
   return TILE_32x256;
+}
+
+bool conv_forced_tile_extent(int tile, int cout, int* bch, int* bpx) {
+  int c = 0, p = 0;
+  switch (tile) {
+    case TILE_128x128: c = 128; p = 128; break;
+    case TILE_64x128: case TILE_64x128W8: c = 64; p = 128; break;
+    case TILE_32x256: c = 32; p = 256; break;
+    case TILE_64x256: c = 64; p = 256; break;
+    case TILE_HALO: case TILE_HALO8W: case TILE_HALO4W: case TILE_LEAN: c = cout > 64 ? 128 : 64; p = 128; break;
+    case TILE_HALOWIDE: case TILE_LEAN128x8: case TILE_LEAN128x16: c = 128; p = 256; break;
+    case TILE_LEAN64x16: case TILE_SLAB: c = 64; p = 256; break;
+    case TILE_C32: c = 32; p = 256; break;
+    default: return false;
+  }
+  if (bch) *bch = c;
+  if (bpx) *bpx = p;
+  return true;
 }
 
 int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {

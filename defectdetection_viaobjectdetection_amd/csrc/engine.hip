@@ -1241,6 +1241,17 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   hipStream_t s = (hipStream_t)stream;
   const int cout_v = transposed ? 4 * cout : cout;
   const int cout_pad = conv_cout_pad(cout_v);
+  if (force_tile >= 0) {
+    // A forced tile must be one a launcher implements, and its channel extent must stay inside the cout_pad weight / bias
+    // rows allocated below (an experimental 256-row channel tile against 128-row padding was a GPU page fault: DESIGN.md)
+    int bch = 0, bpx = 0;
+    if (!conv_forced_tile_extent(force_tile & 0xff, cout_v, &bch, &bpx))
+      return set_err(M355_ERR_INVALID, "unknown forced tile id " + std::to_string(force_tile & 0xff));
+    if ((cout_v + bch - 1) / bch * bch > cout_pad)
+      return set_err(M355_ERR_INVALID, "forced tile reads " + std::to_string((cout_v + bch - 1) / bch * bch) +
+                                           " weight rows, the packed buffer has " + std::to_string(cout_pad));
+  }
+  if (cin <= 0 || cout <= 0 || B <= 0 || H <= 0 || W <= 0) return set_err(M355_ERR_INVALID, "non-positive shape");
   const int Kpad = transposed ? conv_kpad(cin, 1) : conv_kpad(cin, k);
   std::vector<half_t> rows((size_t)cout_pad * Kpad, (half_t)0.f);
   std::vector<float> bias(cout_pad, 0.f);
@@ -1264,7 +1275,7 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
   ConvArgs a{};
   a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * cin; a.ldx = cin; a.Hi = H; a.Wi = W; a.Cin = cin;
-  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = act; a.out_f32 = out_f32;
+  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = act; a.out_f32 = out_f32; a.w_rows = cout_pad;
   a.y = d_y;
   if (transposed) {
     a.ksize = 1; a.stride = 1; a.pad = 0; a.Ho = H; a.Wo = W; a.Cout = 4 * cout; a.convt_co = cout;
@@ -1344,7 +1355,7 @@ int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const floa
   HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
   ConvArgs a{};
   a.x = (const half_t*)d_dy; a.x_bstride = (long)Ho * Wo * cout; a.ldx = cout; a.Hi = Ho; a.Wi = Wo; a.Cin = cout;
-  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = 0;
+  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = 0; a.w_rows = cout_pad;
   a.y = d_dx; a.y_bstride = (long)H * W * cin; a.ldy = cin; a.Ho = H; a.Wo = W; a.Cout = cin;
   a.ksize = k; a.stride = 1; a.pad = pad; a.tmode = (stride == 2) ? 1 : 0;
   a.M = B * H * W;

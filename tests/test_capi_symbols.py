@@ -45,3 +45,19 @@ def test_no_device_is_a_loud_error():
     rc = _capi.lib.m355_create(ctypes.byref(desc), ctypes.byref(h))
     assert rc == -2 and not h.value
     assert b"no CPU fallback" in _capi.lib.m355_last_error(None)
+
+
+def test_forced_tile_ids_are_validated_before_any_device_work():
+    """m355_conv2d_fwd(force_tile=...) is a debug entry: a tile id no launcher implements (the experimental 256-row channel
+    tiles that once faulted the GPU) must come back as M355_ERR_INVALID (-1), decided on the host
+    before any allocation or launch -- so the check runs here, without a GPU."""
+    import numpy as np
+    from defectdetection_viaobjectdetection_amd import _capi
+    w = np.zeros((128, 64, 1, 1), np.float32)
+    b = np.zeros(128, np.float32)
+    fake_dev = ctypes.c_void_p(0x1000)   # never dereferenced: the rejection precedes every HIP call
+    for bad in (4, 6, 7, 26, 200, 255, 0x100 | 7):
+        rc = _capi.lib.m355_conv2d_fwd(fake_dev, 1, 8, 8, 64, w.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
+                                       128, 1, 1, 1, None, fake_dev, 0, bad, None)
+        assert rc == -1, (bad, rc)
+        assert b"forced tile" in _capi.lib.m355_last_error(None)
