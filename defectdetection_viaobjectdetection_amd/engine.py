@@ -52,6 +52,17 @@ class SegEngine:
         self.specs: List[ConvSpec] = conv_specs(scale, nc)
         self._check_graph()
 
+    @staticmethod
+    def proto_is_composed(scale: str) -> bool:
+        """True when the engine runs Proto's ConvTranspose + 3x3 conv as four composed 2x2 phase convolutions
+        (engine.hip build_graph: prototype width a multiple of 64 and M355_NO_PROTOFUSE unset)."""
+        import math
+        import os
+        from .spec import SCALES
+        _, width, maxc = SCALES[scale]
+        npr = int(math.ceil(min(256, maxc) * width / 8) * 8)
+        return npr % 64 == 0 and "M355_NO_PROTOFUSE" not in os.environ
+
     # ------------------------------------------------------------------ graph / weights
     def conv_infos(self) -> List[ConvInfo]:
         out = []

@@ -32,11 +32,14 @@ def test_forward_and_postprocess_parity(scale, nc, shape, batch, cuda_device):
     sd = synthetic_state_dict(scale, nc, seed=11, cls_bias=-2.5)
     eng = SegEngine(scale, nc, shape, max_batch=batch)
     eng.load_state_dict(sd)
+    import engine_format_oracle as efo
     oracle = build_oracle(scale, nc, sd)
+    fmt = efo.to_engine_format(build_oracle(scale, nc, sd), composed_proto=SegEngine.proto_is_composed(scale))
     imgs = synthetic_bscans(batch, shape[0], shape[1], seed=5)
     x = torch.from_numpy(imgs.transpose(0, 3, 1, 2).copy()).float() / 255.0
     with torch.no_grad():
         o_preds, o_protos = oracle(x)
+        f_preds, f_protos = fmt(x)
     preds, protos = eng.forward(torch.from_numpy(imgs).to(cuda_device))
     torch.cuda.synchronize()
     A = o_preds.shape[2]
@@ -46,8 +49,22 @@ def test_forward_and_postprocess_parity(scale, nc, shape, batch, cuda_device):
     e_box = float((gp[..., :4] - op[..., :4]).abs().median())
     e_sc = float((gp[..., 4:4 + nc] - op[..., 4:4 + nc]).abs().max())
     e_mc = rel_l2(gp[..., 4 + nc:], op[..., 4 + nc:])
-    print(f"{scale} nc={nc} {shape} b={batch}: proto {e_pr:.2e} coef {e_mc:.2e} box-median {e_box:.4f}px score-max {e_sc:.2e}")
-    assert e_pr <= 1e-2 and e_mc <= 1e-2 and e_box <= 0.5 and e_sc <= 2e-2
+    # the engine-format oracle (an independent CPU implementation of the same number format) against the fp32 oracle is
+    # what fp16 storage costs on these inputs; the HIP path is held to that: rms x 1.25, maxima (heavy-tailed) x 2
+    fp = f_preds.permute(0, 2, 1)
+    rms = lambda a, b: float((a - b).pow(2).mean().sqrt())
+    floor = dict(sc=float((fp[..., 4:4 + nc] - op[..., 4:4 + nc]).abs().max()), box=float((fp[..., :4] - op[..., :4]).abs().max()),
+                 sc_rms=rms(fp[..., 4:4 + nc], op[..., 4:4 + nc]), box_rms=rms(fp[..., :4], op[..., :4]))
+    got = dict(sc=e_sc, box=float((gp[..., :4] - op[..., :4]).abs().max()), sc_rms=rms(gp[..., 4:4 + nc], op[..., 4:4 + nc]),
+               box_rms=rms(gp[..., :4], op[..., :4]))
+    dsc = (gp[..., 4:4 + nc] - op[..., 4:4 + nc]).abs().flatten()
+    p99 = float(dsc.kthvalue(max(1, int(dsc.numel() * 0.99)))[0])
+    print(f"{scale} nc={nc} {shape} b={batch}: proto {e_pr:.2e} coef {e_mc:.2e} box median {e_box:.4f} px | HIP vs fp32: score max {got['sc']:.2e} "
+          f"rms {got['sc_rms']:.2e} p99 {p99:.2e}, box max {got['box']:.3f} rms {got['box_rms']:.4f} px | format floor: score max {floor['sc']:.2e} "
+          f"rms {floor['sc_rms']:.2e}, box max {floor['box']:.3f} rms {floor['box_rms']:.4f} px")
+    assert e_pr <= 1e-2 and e_mc <= 1e-2 and e_box <= 0.5 and p99 <= 2e-3
+    assert got["sc"] <= 2 * floor["sc"] and got["box"] <= 2 * floor["box"]
+    assert got["sc_rms"] <= 1.25 * floor["sc_rms"] + 1e-5 and got["box_rms"] <= 1.25 * floor["box_rms"] + 1e-3
     # NMS (+ multi-class offsets) bit-exact on identical preds; masks >= 99.5 %
     for conf, iou, max_det in ((0.25, 0.7, 300), (0.05, 0.5, 20)):
         dets, counts, masks = eng.postprocess(preds, protos, conf, iou, max_det)
