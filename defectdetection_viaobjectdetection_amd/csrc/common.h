@@ -69,11 +69,11 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_LEAN = 21, TILE_LEAN128x8 = 22, TILE_LEAN64x16 = 23, TILE_LEAN128x16 = 24, TILE_SLAB = 25 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_LEAN = 21, TILE_LEAN128x8 = 22, TILE_LEAN64x16 = 23, TILE_LEAN128x16 = 24, TILE_SLAB = 25, TILE_M32 = 26, TILE_M32_128 = 27, TILE_M32_64x16 = 28, TILE_M32_64x8 = 29 };
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {
-  bool no_fast_epi, no_wide, no_persist, stem_gather, lean;
+  bool no_fast_epi, no_wide, no_persist, stem_gather, lean, no_m32;
   int persist, halo_variant, smallm;
 };
 const Knobs& knobs();
@@ -98,6 +98,9 @@ int launch_conv3x3_halo(const ConvArgs& a, int variant, hipStream_t s);  // vari
 // 128 ch x 16x16 px, K depth 32 per step (conv3x3_wide.hip)
 bool conv3x3_wide_ok(const ConvArgs& a);
 int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s);
+// v_mfma_f32_32x32x16_f16 halo kernel (conv3x3_m32.hip); which: 0 = by shape, 1 = <128 ch, 8 rows>, 2 = <64, 16>, 3 = <64, 8>
+bool conv3x3_m32_ok(const ConvArgs& a);
+int launch_conv3x3_m32(const ConvArgs& a, int which, hipStream_t s);
 // narrow maps (W <= 26): slabs of full-width rows, linear pixel groups (conv3x3_small.hip)
 bool conv3x3_slab_ok(const ConvArgs& a);
 int launch_conv3x3_slab(const ConvArgs& a, hipStream_t s);

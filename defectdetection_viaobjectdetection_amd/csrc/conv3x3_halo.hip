@@ -373,6 +373,14 @@ int launch_conv3x3_halo(const ConvArgs& a0, int variant, hipStream_t s) {
   if (knobs().no_fast_epi) a.dbg |= 256;
   if (variant == TILE_SLAB - TILE_HALO) return launch_conv3x3_slab(a, s);
   if (!conv3x3_halo_ok(a)) return -1;
+  if (variant >= TILE_M32 - TILE_HALO && variant <= TILE_M32_64x8 - TILE_HALO) return launch_conv3x3_m32(a, variant - (TILE_M32 - TILE_HALO), s);
+  // by shape (measured at batch 32, tools/conv3_sweep.py): the wide kernel where its 16x16-pixel tiles fit (80x80 and
+  // larger maps, Cout >= 128: equal to the 32x32x16 kernel there); the 32x32x16 kernel on the smaller maps (128 -> 128 at
+  // 40x40: 25.8 -> 21.7 us, 256 -> 224: 79.7 -> 68.8 us, 64 -> 64: 10.0 -> 8.7 us); the 8-row halo kernel for 64-channel
+  // layers on large maps (24.6 us against 26.0)
+  if (variant == 0 && !knobs().no_m32 && conv3x3_m32_ok(a) && !(conv3x3_wide_ok(a) && !knobs().no_wide) &&
+      (a.Cout > 64 || a.Hi * a.Wi <= 1600))
+    return launch_conv3x3_m32(a, 0, s);
   if (variant == 3 || (variant == 0 && conv3x3_wide_ok(a) && !knobs().no_wide)) return launch_conv3x3_wide(a, s);
   if (variant >= 5) return launch_conv3x3_lean(a, variant - 5, s);
   if (variant == 0 && knobs().lean) return launch_conv3x3_lean(a, 0, s);   // measured equal to the K-64 kernels below

@@ -772,6 +772,7 @@ const Knobs& knobs() {
     v.no_fast_epi = getenv("M355_NO_FAST_EPI") != nullptr;
     v.no_wide = getenv("M355_NO_WIDE") != nullptr;
     v.lean = getenv("M355_LEAN") != nullptr;
+    v.no_m32 = getenv("M355_NO_M32") != nullptr;
     v.no_persist = getenv("M355_NO_PERSIST") != nullptr;
     v.stem_gather = getenv("M355_STEM_GATHER") != nullptr;
     v.persist = getenv("M355_PERSIST") ? atoi(getenv("M355_PERSIST")) : 0;
@@ -806,6 +807,10 @@ bool conv_forced_tile_extent(int tile, int cout, int* bch, int* bpx) {
     case TILE_HALOWIDE: case TILE_LEAN128x8: case TILE_LEAN128x16: c = 128; p = 256; break;
     case TILE_LEAN64x16: case TILE_SLAB: c = 64; p = 256; break;
     case TILE_C32: c = 32; p = 256; break;
+    case TILE_M32: c = cout > 64 ? 128 : 64; p = 256; break;
+    case TILE_M32_128: c = 128; p = 128; break;
+    case TILE_M32_64x16: c = 64; p = 256; break;
+    case TILE_M32_64x8: c = 64; p = 128; break;
     default: return false;
   }
   if (bch) *bch = c;

@@ -697,7 +697,7 @@ void annotate_ops(m355_engine* e) {
         op.tile = conv_pick_tile(cout_v, e->desc.max_batch * Ho * Wo);
         if (k == 1 && op.tile == TILE_128x128 && getenv("M355_K1_TILE")) op.tile = atoi(getenv("M355_K1_TILE"));
         if (op.decode) op.tile = TILE_128x128;   // the whole 64 + nc + nm row of a pixel in one channel tile
-        bool wide = false;
+        bool wide = false, m32 = false;
         {
           ConvArgs probe{};
           probe.ksize = p.k; probe.stride = p.stride; probe.pad = p.k / 2; probe.out_f32 = (op.out_ext == 1);
@@ -707,6 +707,10 @@ void annotate_ops(m355_engine* e) {
           if (op.kind == OP_CONV && conv3x3_halo_ok(probe) && !getenv("M355_NO_HALO")) op.tile = TILE_HALO;
           wide = op.tile == TILE_HALO && conv3x3_wide_ok(probe) && !getenv("M355_NO_WIDE");
           probe.Kpad = p.Kpad;
+          probe.M = e->desc.max_batch * Ho * Wo; probe.x_bstride = (long)ti.H * ti.W * ti.C; probe.ldx = ti.C;
+          // the same rule launch_conv3x3_halo applies (conv3x3_halo.hip): 32x32x16 kernel on the maps the wide tiles do not fit
+          m32 = op.tile == TILE_HALO && !wide && !getenv("M355_NO_M32") && conv3x3_m32_ok(probe) && (cout_v > 64 || ti.H * ti.W <= 1600);
+          probe.ldx = 8;
           if (op.kind == OP_CONV && conv3x3_c32_ok(probe) && !getenv("M355_NO_C32")) op.tile = TILE_C32;
           if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
             op.tile = TILE_SLAB;
@@ -717,6 +721,8 @@ void annotate_ops(m355_engine* e) {
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_slab<64ch,rows>");
         else if (wide)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_wide<128ch,16x16px>");
+        else if (m32)
+          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_m32<%s,8x16px>", cout_v > 64 ? "128ch" : "64ch");
         else if (op.tile == TILE_HALO && getenv("M355_LEAN"))
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_lean<%s>", cout_v > 64 ? "128ch,8x16px" : "64ch,16x16px");
         else if (op.tile == TILE_HALO)

@@ -96,6 +96,23 @@ CONV_CASES = [
     (1, 26, 26, 64, 128, 3, 1, 1, True, 25),        # widest map: R = 9, last slab 8 rows
     (2, 13, 7, 128, 64, 3, 1, 1, False, 25),        # odd sizes, groups straddling up to three rows
     (300, 20, 20, 64, 64, 3, 1, 1, False, 25),      # 600 tiles on 512 slots: blocks walk two tiles
+    # v_mfma_f32_32x32x16_f16 halo kernel (conv3x3_m32.hip): 27 = 128 ch x 8 rows, 28 = 64 ch x 16 rows, 29 = 64 ch x 8 rows,
+    # 26 = by shape
+    (2, 32, 32, 128, 128, 3, 1, 1, True, 27),       # two chunks (both patch buffers), residual
+    (1, 80, 80, 128, 224, 3, 1, 1, False, 27),      # ragged channel tile (224 = 128 + 96)
+    (2, 40, 40, 128, 128, 3, 1, 1, True, 27),       # 2.5 column tiles
+    (2, 72, 56, 64, 128, 3, 1, 1, True, 27),        # one chunk (single patch buffer), partial tiles in both directions
+    (3, 48, 32, 192, 256, 3, 1, 0, False, 27),      # three chunks (odd: the unpaired tail chunk), two channel tiles, no act
+    (2, 40, 40, 256, 224, 3, 1, 1, False, 27),      # four chunks
+    (1, 8, 16, 64, 128, 3, 1, 1, False, 27),        # a single tile: every image border inside one patch
+    (2, 80, 80, 64, 64, 3, 1, 1, True, 28),
+    (2, 72, 56, 64, 64, 3, 1, 1, True, 28),         # partial spatial tiles
+    (1, 80, 80, 128, 96, 3, 1, 0, False, 28),       # two chunks, two channel tiles, the second half full (96 = 64 + 32)
+    (2, 40, 40, 64, 64, 3, 1, 1, True, 29),
+    (2, 24, 40, 192, 64, 3, 1, 1, False, 29),       # three chunks
+    (1, 15, 30, 64, 72, 3, 1, 1, True, 29),         # odd sizes, Cout not a multiple of 16
+    (6, 160, 160, 64, 64, 3, 1, 1, False, 26),      # by shape
+    (2, 40, 40, 256, 256, 3, 1, 1, True, 26),
 ]
 
 
