@@ -7,9 +7,16 @@ the C-ABI.  Inputs are resident in HBM before the timed region.  One process per
 the image batch across ranks with NO data-path collective (weak scaling: 32 images per GPU per step);
 torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
 
+The input rotates over 8 distinct device-resident batches (315 MB > the 256 MiB Infinity Cache), so every step reads its
+images from HBM.  `value` is PIPELINED THROUGHPUT: two batches are in flight on two engine instances and the
+post-processing of a batch overlaps later forwards, so `ms_per_step` is the step period, not a latency.
+
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, measured live with HIP events recorded
-on the launch stream inside the timed region) and, at N=1, `cpu_baseline` (the CPU oracle, kind "port",
-timed on this node's host cores on a bounded sample of the same workload).
+on the launch stream inside the timed region), at N=1 `cpu_baseline` (the CPU oracle, kind "port",
+timed on this node's host cores on a bounded sample of the same workload, batch 32) and `train_step`: the training
+path's step on a synthetic device-resident batch after the inference measurement -- N=1: YOLOv8s-seg, batch 64 @640
+(BASELINE config 3) with the forward / loss / backward / optimizer split; N>1: YOLOv8m-seg data parallel, 64 images per
+GPU (config 4), with the gradient all-reduce time alone, the part of it not hidden under backward and the overlap fraction.
 """
 import argparse
 import json
@@ -32,6 +39,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
     ap.add_argument("--scale", default="s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the train_step measurement")
+    ap.add_argument("--input-batches", type=int, default=8,
+                    help="distinct device-resident input batches the steps rotate over (8 x 39 MB > the 256 MiB Infinity Cache)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-op HIP events")
     ap.add_argument("--no-overlap", action="store_true",
                     help="run post-processing on the forward stream instead of overlapping it with the next batch")
@@ -90,7 +100,8 @@ def main():
         e_.load_state_dict(sd)
         engs.append(e_)
     eng = engs[0]
-    imgs = torch.from_numpy(synthetic_bscans(B, seed=1000 + rank)).cuda()
+    n_in = max(1, args.input_batches)
+    imgs_all = [torch.from_numpy(synthetic_bscans(B, seed=1000 + 97 * rank + j)).cuda() for j in range(n_in)]
     conf, iou, max_det = 0.25, 0.7, 300
 
     # persistent output buffers (caller-owned), allocated once outside the timed region
@@ -125,7 +136,7 @@ def main():
             sf.wait_event(ev_post[e][k])          # the post-processing that last read this buffer set is done
         if (alone or step.prev_alone) and last_fwd[0] is not None:
             sf.wait_event(last_fwd[0])            # serialise against the previous forward (other engine's stream)
-        check(lib.m355_forward(engs[e]._h, P(imgs), B, P(preds[e][k]), P(protos[e][k]), C.c_void_p(sf.cuda_stream)), engs[e]._h)
+        check(lib.m355_forward(engs[e]._h, P(imgs_all[i % n_in]), B, P(preds[e][k]), P(protos[e][k]), C.c_void_p(sf.cuda_stream)), engs[e]._h)
         ev_fwd[e][k].record(sf)
         last_fwd[0] = ev_fwd[e][k]
         step.prev_alone = alone
@@ -186,7 +197,10 @@ def main():
         "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "fp16", "data": "synthetic",
         "config": {"workload": f"YOLOv8{args.scale}-seg inference (forward + NMS + masks), {B} synthetic 640x640 "
-                               f"B-scans per GPU per step, nc=1, seeded synthetic weights",
+                               f"B-scans per GPU per step, nc=1, seeded synthetic weights; pipelined throughput, "
+                               f"{n_eng} batch(es) in flight (ms_per_step is the step period, not a latency); inputs rotate "
+                               f"over {n_in} HBM-resident batches ({n_in * B * 640 * 640 * 3 / 2 ** 20:.0f} MiB)",
+                   "input_batches": n_in,
                    "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}, no collective",
                    "conf": conf, "iou": iou, "max_det": max_det,
                    "mean_detections_per_image": round(float(counts_b[0][0].float().mean()), 2),
@@ -239,15 +253,133 @@ def main():
             out["forward_ms_per_step_events"] = round(fwd_ms, 4)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scale, sd)
+    if not args.no_train:
+        for e_ in engs:
+            e_.close()
+        del preds, protos, dets, masks, imgs_all
+        torch.cuda.empty_cache()
+        try:
+            ts = train_step_bench(world, dist)
+        except Exception as ex:  # noqa: BLE001 -- the inference line must still be printed
+            ts = {"error": f"{type(ex).__name__}: {ex}"}
+        if rank == 0:
+            out["train_step"] = ts
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
 
+def train_step_bench(world, dist, steps=4, warm=2):
+    """One optimizer step of the training path on a synthetic device-resident batch (images + 2 boxes / masks per image).
+    N=1: YOLOv8s-seg, batch 64 @640 (BASELINE config 3); N>1: YOLOv8m-seg, 64 images per GPU, data parallel (config 4).
+    Wall-clock between device synchronisations; every rank runs it, rank 0 reports (max over ranks for N>1)."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from defectdetection_viaobjectdetection_amd._capi import check, lib
+    from defectdetection_viaobjectdetection_amd.loss import segmentation_loss
+    from defectdetection_viaobjectdetection_amd.sharding import GradBucketReducer
+    from defectdetection_viaobjectdetection_amd.spec import init_state_dict
+    from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
+    scale, B, S = ("s", 64, 640) if world == 1 else ("m", 64, 640)
+    dev = torch.device("cuda", torch.cuda.current_device())
+    eng = TrainEngine(scale, 1, (S, S), B, device=dev.index)
+    eng.load_state_dict(init_state_dict(scale, 1, seed=0))
+    rng = np.random.default_rng(int(os.environ.get("RANK", "0")))
+    imgs = torch.from_numpy(rng.integers(0, 255, (B, S, S, 3), dtype=np.uint8)).to(dev)
+    n = 2 * B
+    boxes = torch.tensor(np.stack([rng.uniform(.3, .7, n), rng.uniform(.3, .7, n), rng.uniform(.1, .3, n), rng.uniform(.1, .3, n)], 1),
+                         dtype=torch.float32).to(dev)
+    masks = torch.zeros(B, S // 4, S // 4, device=dev)
+    masks[:, 40:80, 40:80] = 1
+    masks[:, 60:70, 60:70] = 2
+    batch = {"batch_idx": torch.arange(B).repeat_interleave(2).float().to(dev), "cls": torch.zeros(n, device=dev), "bboxes": boxes,
+             "masks": masks}
+    m1 = torch.zeros(eng.n_train, device=dev)
+    m2 = torch.zeros(eng.n_train, device=dev)
+    ema = eng.flat_params.clone()
+    reducer = GradBucketReducer(eng.flat_grads, eng.grad_spans()) if world > 1 else None
+    st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
+
+    def tick():
+        torch.cuda.synchronize()
+        return time.perf_counter()
+
+    def one_step(it, tim, overlap=True, comm=True):
+        t0 = tick()
+        raw, protos = eng.forward(imgs)
+        t1 = tick()
+        r = raw.detach().clone().requires_grad_(True)
+        p = protos.detach().float().requires_grad_(True)
+        loss, _ = segmentation_loss(r, p, batch, 1, (S, S))
+        (loss * 128.0).backward()
+        t2 = tick()
+        if reducer is not None and comm:
+            reducer.reset()
+        eng.backward(r.grad, p.grad, on_ready=reducer.mark_ready if (reducer is not None and comm and overlap) else None)
+        if reducer is not None and comm:
+            reducer.finish()
+        t3 = tick()
+        check(lib.m355_adamw_step(eng.flat_params.data_ptr(), eng.flat_grads.data_ptr(), m1.data_ptr(), m2.data_ptr(), ema.data_ptr(),
+                                  eng.group.data_ptr(), eng.n_train, 1e-4, 1e-4, 0.9, 0.999, 1e-8, 5e-4, it + 1, 1 / (128.0 * world), 0.999,
+                                  st()))
+        t4 = tick()
+        eng.repack()
+        t5 = tick()
+        for k, v in zip(("fwd", "loss", "bwd", "opt", "repack"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
+            tim[k] = tim.get(k, 0.0) + v
+        return float(loss)
+
+    def run(overlap, comm):
+        tim = {}
+        for it in range(warm):
+            one_step(it, {}, overlap, comm)
+        if dist is not None:
+            dist.barrier()
+        t0 = tick()
+        for it in range(steps):
+            loss = one_step(warm + it, tim, overlap, comm)
+        total = tick() - t0
+        return total / steps, {k: v / steps for k, v in tim.items()}, loss
+
+    per_step, tim, loss = run(True, True)
+    res = {"config": f"YOLOv8{scale}-seg training step, {B} synthetic {S}x{S} images per GPU, nc=1, fresh weights, AdamW; "
+                     f"{'single GPU' if world == 1 else f'data parallel x{world}, SUM all-reduce of the flat fp32 gradient in 32 MiB buckets under backward'}",
+           "steps": steps, "warmup": warm, "ms_per_step": round(per_step * 1e3, 2), "images_per_s": round(world * B / per_step, 1),
+           # SURVEY 8d: forward conv FLOPs per image @640, nc=1; a training step ~ 3x (forward + dgrad + wgrad)
+           "tflops": round(3 * {"n": 11.34, "s": 39.92, "m": 104.28}[scale] * 1e9 * B / per_step / 1e12, 1),
+           "forward_ms": round(tim["fwd"] * 1e3, 2), "loss_ms": round(tim["loss"] * 1e3, 2), "backward_ms": round(tim["bwd"] * 1e3, 2),
+           "optimizer_ms": round(tim["opt"] * 1e3, 2), "repack_ms": round(tim["repack"] * 1e3, 2), "loss": round(loss, 4)}
+    if world > 1:
+        _, tim_nc, _ = run(False, False)                     # backward without any exchange
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = tick()
+        for _ in range(steps):                               # the exchange alone: one SUM all-reduce of the whole flat buffer
+            dist.all_reduce(eng.flat_grads, op=dist.ReduceOp.SUM)
+        comm_alone = (tick() - t0) / steps
+        exposed = max(tim["bwd"] - tim_nc["bwd"], 0.0)
+        vals = torch.tensor([per_step, comm_alone, exposed, tim["bwd"], tim_nc["bwd"]], dtype=torch.float64, device=dev)
+        dist.all_reduce(vals, op=dist.ReduceOp.MAX)
+        per_step, comm_alone, exposed, bwd_c, bwd_nc = [float(v) for v in vals]
+        res.update({"ms_per_step": round(per_step * 1e3, 2), "images_per_s": round(world * B / per_step, 1),
+                    "gradient_mbytes": round(eng.n_train * 4 / 1e6, 1), "allreduce_ms": round(comm_alone * 1e3, 3),
+                    "allreduce_exposed_ms": round(exposed * 1e3, 3), "backward_ms": round(bwd_c * 1e3, 2),
+                    "backward_no_exchange_ms": round(bwd_nc * 1e3, 2),
+                    "overlap_frac": round(min(max(1.0 - exposed / max(comm_alone, 1e-9), 0.0), 1.0), 3),
+                    "buckets": len(reducer.launched)})
+    del eng
+    torch.cuda.empty_cache()
+    return res
+
+
 def pmc_traffic(kernel_label):
     """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes of this same command
     (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     try:
         with open(path) as f:
             k = json.load(f)["kernels"].get(kernel_label)
@@ -272,7 +404,7 @@ def host_cores():
 
 def cpu_baseline(scale, sd):
     """The CPU oracle (a restatement of the Ultralytics CPU path; kind "port") on this node's host cores,
-    bounded sample: batches of 8 of the same synthetic workload, 1 warm-up + timed iterations for ~15 s."""
+    bounded sample: batches of 32 of the same synthetic workload, 1 warm-up + timed iterations for ~15-20 s."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yolov8_seg_oracle as orc
@@ -282,7 +414,7 @@ def cpu_baseline(scale, sd):
     model = orc.SegmentationModel(scale, 1)
     model.load_state_dict(sd)
     model.eval()
-    bs = 8
+    bs = 32
     imgs = synthetic_bscans(bs, seed=1000)
     x = torch.from_numpy(imgs.transpose(0, 3, 1, 2).copy()).float() / 255.0
 
@@ -299,7 +431,7 @@ def cpu_baseline(scale, sd):
         one()
         n += 1
         el = time.perf_counter() - t0
-        if el > 15.0 or n >= 40:
+        if el > 15.0 or n >= 12:
             break
     return {"value": round(n * bs / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": f"{n} iterations of batch {bs} (640x640 synthetic B-scans) after 1 warm-up, PyTorch-CPU fp32 "

@@ -10,6 +10,8 @@ LABELS = {
     "conv_igemm_kernel<4, 4, 2, 2, 2>": "conv_igemm<128x128,k2,phase+1x1>", "conv_igemm_kernel<4, 2, 1, 4, 2>": "conv_igemm<64x128,k2,phase>",
     "conv_igemm_kernel<4, 2, 1, 4, 3>": "conv_igemm<64x128,k3>", "conv_igemm_kernel<4, 2, 1, 4, 1>": "conv_igemm<64x128,k1>",
     "conv_igemm_kernel<2, 4, 1, 4, 3>": "conv_igemm<32x256,k3>", "conv_igemm_kernel<2, 4, 1, 4, 1>": "conv_igemm<32x256,k1>",
+    "conv3x3_m32_kernel<128, 2>": "conv3x3_m32<128ch,8x16px>", "conv3x3_m32_kernel<64, 1>": "conv3x3_m32<64ch,8x16px>",
+    "conv3x3_m32_kernel<64, 2>": "conv3x3_m32<64ch,16x16px>",
     "conv3x3_wide_kernel": "conv3x3_wide<128ch,16x16px>", "conv3x3_slab_kernel": "conv3x3_slab<64ch,rows>", "conv3x3_c32_kernel": "conv3x3_c32<32ch,16x16px>",
     "stem_rows_kernel": "stem_conv<k3s2,u8,mfma>", "augment_kernel": "augment",
     "stem_kernel": "stem_conv<k3s2,u8,mfma>", "head_decode_kernel": "head_decode", "sppf_pool_kernel": "sppf_pool",
@@ -44,16 +46,21 @@ def load(path, counter):
     return {k: (v[0], len(v[1])) for k, v in per.items()}
 
 
-fetch = load(sys.argv[1], "FETCH_SIZE")
-write = load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in sorted(set(fetch) | set(write)):
-    f, nf = fetch.get(k, (0.0, 0))
-    w, nw = write.get(k, (0.0, 0))
-    n = max(nf, nw, 1)
-    out[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * f * 1024 / max(nf, 1), "write_bytes_per_launch": w * 1024 / max(nw, 1)}
-    out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
-json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled per the gfx950 correction; "
-                   "bench.py --serial --steps 2 --warmup 1 --batch 32", "kernels": out}, open(sys.argv[3], "w"), indent=1)
-for k, v in out.items():
-    print(f"{k:28s} launches {v['launches']:4d}  HBM/launch {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB")
+def main():
+    fetch = load(sys.argv[1], "FETCH_SIZE")
+    write = load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        f, nf = fetch.get(k, (0.0, 0))
+        w, nw = write.get(k, (0.0, 0))
+        n = max(nf, nw, 1)
+        out[k] = {"launches": n, "fetch_bytes_per_launch": 2.0 * f * 1024 / max(nf, 1), "write_bytes_per_launch": w * 1024 / max(nw, 1)}
+        out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH doubled per the gfx950 correction; "
+                       "bench.py --serial --steps 2 --warmup 1 --batch 32", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:28s} launches {v['launches']:4d}  HBM/launch {v['hbm_bytes_per_launch'] / 1e6:9.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
