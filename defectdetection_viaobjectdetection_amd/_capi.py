@@ -53,7 +53,8 @@ class WgradLaunchArgs(C.Structure):
     _fields_ = [("dz", C.c_void_p), ("dz_bstride", C.c_int64), ("lddz", C.c_int32), ("x", C.c_void_p),
                 ("x_bstride", C.c_int64), ("ldx", C.c_int32), ("hi", C.c_int32), ("wi", C.c_int32), ("cin", C.c_int32),
                 ("ho", C.c_int32), ("wo", C.c_int32), ("cout", C.c_int32), ("ksize", C.c_int32), ("stride", C.c_int32),
-                ("pad", C.c_int32), ("batch", C.c_int32), ("dw", C.c_void_p), ("zero_page", C.c_void_p)]
+                ("pad", C.c_int32), ("batch", C.c_int32), ("dw", C.c_void_p), ("zero_page", C.c_void_p), ("ws", C.c_void_p),
+                ("ws_bytes", C.c_int64)]
 
 
 # symbol -> (restype, argtypes); every entry of include/mi355yolo.h
@@ -86,7 +87,10 @@ SIGNATURES = {
     "m355_conv2d_dgrad": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_conv2d_wgrad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_bn_silu_train_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P]),
-    "m355_bn_silu_train_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P]),
+    "m355_bn_silu_train_bwd": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, _P, _P, _P]),
+    "m355_bn_workspace_floats": (C.c_size_t, [C.c_int]),
+    "m355_wgrad_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "m355_grad_sumsq_workspace_floats": (C.c_size_t, []),
     "m355_convt2x2_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "m355_stem_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, _P, _P]),
     "m355_sppf_pool": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
@@ -98,7 +102,7 @@ SIGNATURES = {
     "m355_bn_train_fwd_launch": (C.c_int, [_P, C.c_int64, C.c_int32, C.c_int32, _P, _P, C.c_float, C.c_int32, _P, C.c_int32,
                                            _P, C.c_int32, _P, _P, _P, _P, _P, C.c_float, _P]),
     "m355_bn_train_bwd_launch": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32,
-                                           _P, C.c_int32, _P, _P]),
+                                           _P, C.c_int32, _P, _P, _P]),
     "m355_adamw_step": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                   C.c_float, C.c_int32, C.c_float, C.c_float, _P]),
     "m355_sgd_step": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float,

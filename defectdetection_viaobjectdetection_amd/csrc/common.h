@@ -136,10 +136,14 @@ size_t nms_workspace_bytes(int B, int A);
 int launch_proto_masks(const float* dets, const int* counts, const half_t* protos, int B, int max_det,
                        int nm, int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s);
 
-// weight gradient (conv_wgrad.hip): dw fp32 [Cout][k*k*Cin] (KRSC), zeroed + accumulated by the call
+// weight gradient (conv_wgrad.hip): dw fp32 [Cout][k*k*Cin] (KRSC).  Split-K partial slabs go to the caller's workspace
+// (conv_wgrad_workspace_bytes) and are added in split order: bitwise reproducible.  -3: workspace missing / too small.
+size_t conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize);
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
                       int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
-                      const half_t* zero, hipStream_t s);
+                      const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s);
+// floats of workspace the train-mode batch-norm launches need for C channels (per-block partial sums + ticket)
+size_t bn_workspace_floats(int C);
 
 // train-mode BatchNorm + SiLU (train_kernels.hip)
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
@@ -150,12 +154,13 @@ int launch_adamw_step(float* p, const float* g, float* m, float* v, float* ema, 
                       float ema_d, hipStream_t s);
 int launch_sgd_step(float* p, const float* g, float* buf, float* ema, const unsigned char* group, long n, float lr,
                     float lr_bias, float momentum, int nesterov, float wd, float grad_mul, float ema_d, hipStream_t s);
-int launch_grad_sumsq(const float* g, long n, float* out, hipStream_t s);
+int launch_grad_sumsq(const float* g, long n, float* out, hipStream_t s);   // out: grad_sumsq_workspace_floats() floats
+size_t grad_sumsq_workspace_floats();
 // mosaic + affine + HSV + flip gather (augment.hip); params: device array of B m355_aug_params
 int launch_augment(const uint8_t* cache, const void* params, uint8_t* out, int B, int H, int W, hipStream_t s);
 int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int ldz, int lddy, int C, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, float* rsum, half_t* dz,
-                             int lddz, int act, hipStream_t s);
+                             int lddz, int act, float* ws, hipStream_t s);
 
 
 // ---------------------------------------------------------------------------------------------------------

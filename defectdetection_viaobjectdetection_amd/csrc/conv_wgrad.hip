@@ -13,8 +13,11 @@
 // 16-byte chunk index of a row is XOR-swizzled with f(row) = 2*(row&3) | ((row>>3)&1)<<3 (source side + read
 // side), found by exhaustive search: every transposed read is bank-conflict free.
 // Block = 128 co x 128 n output tile, 4 waves (64 x 64 each, 16 accumulator tiles), K step = 64 pixels, two
-// LDS stages; the pixel axis is split across blocks (split-K) and partial tiles are added with float atomics
-// (shape: 16 consecutive fp32 per row segment; the dW tensor is tiny next to the activations).
+// LDS stages; the pixel axis is split across blocks (split-K).  DETERMINISTIC reduction: every split writes its partial
+// tile with plain stores into its own slab of a caller-provided workspace ([splitk][Cout][N] fp32) and a second kernel
+// adds the slabs in split order -- bitwise reproducible gradients (float atomics made two runs of one batch differ, and
+// a 60-layer fp16-storage backward amplifies such last-bit differences to 1e-2 in the early layers: DESIGN.md section 8).
+// One split (small layers): the tile goes straight to dW.
 #include "common.h"
 
 namespace m355 {
@@ -26,7 +29,8 @@ struct WgradArgs {
   int ksize, stride, pad;
   int M;        // B*Ho*Wo
   int N;        // ksize*ksize*Cin
-  float* dw;    // [Cout][N] fp32, pre-zeroed, accumulated atomically
+  float* dw;    // [Cout][N] fp32 (written by the reduce kernel, or directly when splitk == 1)
+  float* ws;    // [splitk][Cout][N] fp32 partial slabs (splitk > 1)
   int splitk, steps_per_split;
   const half_t* zero;
 };
@@ -162,8 +166,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
   }
 
-  // ---- split-K reduction: D[row = co 4g+j][col = n l15]
+  // ---- this split's partial tile: D[row = co 4g+j][col = n l15], plain stores into the split's slab (or dW itself)
   const int l15 = lane & 15, g = lane >> 4;
+  float* const outp = a.splitk > 1 ? a.ws + (long)split * a.Cout * a.N : a.dw;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -173,16 +178,53 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co_base + wm * 64 + i * 16 + g * 4 + r;
-        if (co < a.Cout) atomicAdd(a.dw + (long)co * a.N + n, acc[i][j][r]);
+        if (co < a.Cout) outp[(long)co * a.N + n] = acc[i][j][r];
       }
     }
 }
 
+// dW[i] = ws[0][i] + ws[1][i] + ... in split order (fixed association: bitwise reproducible)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, long n, int splitk) {
+  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 4 <= n) {
+      float4v acc = *(const float4v*)(ws + i);
+      for (int s = 1; s < splitk; ++s) {
+        const float4v v = *(const float4v*)(ws + (long)s * n + i);
+        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
+      }
+      *(float4v*)(dw + i) = acc;
+    } else {
+      for (long j = i; j < n; ++j) {
+        float acc = ws[j];
+        for (int s = 1; s < splitk; ++s) acc += ws[(long)s * n + j];
+        dw[j] = acc;
+      }
+    }
+  }
+}
+
+void wgrad_plan(int M, int Cout, int N, int* splitk, int* steps_per_split) {
+  const int tiles = ((Cout + 127) / 128) * ((N + 127) / 128);
+  const int steps_total = (M + KST - 1) / KST;
+  int sk = (1024 + tiles - 1) / tiles;   // ~2 waves of blocks over 256 CUs x 2 resident blocks
+  if (sk > steps_total) sk = steps_total;
+  if (sk < 1) sk = 1;
+  *steps_per_split = (steps_total + sk - 1) / sk;
+  *splitk = (steps_total + *steps_per_split - 1) / *steps_per_split;
+}
+
 }  // namespace
+
+size_t conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize) {
+  int sk = 1, sps = 1;
+  const int N = ksize * ksize * Cin;
+  wgrad_plan(B * Ho * Wo, Cout, N, &sk, &sps);
+  return sk > 1 ? (size_t)sk * Cout * N * sizeof(float) : 0;
+}
 
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
                       int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
-                      const half_t* zero, hipStream_t s) {
+                      const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s) {
   if (ksize < 1 || ksize > 3 || Cin % 8 || Cout % 8 || lddz % 8 || ldx % 8) return -1;
   WgradArgs a{};
   a.dz = dz; a.dz_bstride = dz_bstride; a.lddz = lddz; a.x = x; a.x_bstride = x_bstride; a.ldx = ldx;
@@ -193,14 +235,9 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
   a.N = ksize * ksize * Cin;
   a.dw = dw; a.zero = zero;
   const int tiles = ((Cout + 127) / 128) * ((a.N + 127) / 128);
-  const int steps_total = (a.M + KST - 1) / KST;
-  int splitk = (1024 + tiles - 1) / tiles;   // ~2 waves of blocks over 256 CUs x 2 resident blocks
-  if (splitk > steps_total) splitk = steps_total;
-  if (splitk < 1) splitk = 1;
-  a.steps_per_split = (steps_total + splitk - 1) / splitk;
-  a.splitk = (steps_total + a.steps_per_split - 1) / a.steps_per_split;
-  hipError_t e = hipMemsetAsync(dw, 0, (size_t)Cout * a.N * sizeof(float), s);
-  if (e != hipSuccess) return (int)e;
+  wgrad_plan(a.M, Cout, a.N, &a.splitk, &a.steps_per_split);
+  if (a.splitk > 1 && (!ws || ws_bytes < (size_t)a.splitk * Cout * a.N * sizeof(float))) return -3;   // workspace too small
+  a.ws = ws;
   const dim3 grid(tiles * a.splitk), block(256);
   const int lds = 2 * STAGE2;
   if (ksize == 1) {
@@ -209,6 +246,12 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
     hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, block, lds, s, a);
   } else {
     hipLaunchKernelGGL(conv_wgrad_kernel<3>, grid, block, lds, s, a);
+  }
+  if (a.splitk > 1) {
+    const long n = (long)Cout * a.N;
+    long blocks = (n + 1023) / 1024;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, ws, dw, n, a.splitk);
   }
   return (int)hipGetLastError();
 }

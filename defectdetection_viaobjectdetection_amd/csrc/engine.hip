@@ -1388,10 +1388,22 @@ int m355_conv2d_wgrad(const void* d_x, const void* d_dy, int B, int H, int W, in
   }
   const int pad = k / 2;
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+  const size_t wsb = conv_wgrad_workspace_bytes(B, Ho, Wo, cin, cout, k);
+  float* ws = nullptr;
+  if (wsb) HIP_TRYG(hipMalloc((void**)&ws, wsb));
   const int rc = launch_conv_wgrad((const half_t*)d_dy, (long)Ho * Wo * cout, cout, (const half_t*)d_x, (long)H * W * cin,
-                                   cin, B, H, W, cin, Ho, Wo, cout, k, stride, pad, d_dw, zero_page, (hipStream_t)stream);
+                                   cin, B, H, W, cin, Ho, Wo, cout, k, stride, pad, d_dw, zero_page, ws, wsb, (hipStream_t)stream);
+  const hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+  if (ws) (void)hipFree(ws);
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("wgrad kernel: ") + hipGetErrorString(se));
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "wgrad launch failed: " + std::to_string(rc));
 }
+
+size_t m355_bn_workspace_floats(int C) { return bn_workspace_floats(C); }
+size_t m355_wgrad_workspace_bytes(int32_t batch, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize) {
+  return conv_wgrad_workspace_bytes(batch, ho, wo, cin, cout, ksize);
+}
+size_t m355_grad_sumsq_workspace_floats(void) { return grad_sumsq_workspace_floats(); }
 
 int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const float* d_gamma, const float* d_beta,
                            float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream) {
@@ -1403,11 +1415,11 @@ int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const fl
 
 int m355_bn_silu_train_bwd(const void* d_z, const void* d_dy, int B, int H, int W, int C, const float* d_mean,
                            const float* d_invstd, const float* d_gamma, const float* d_beta, int act, void* d_dz,
-                           float* d_dbeta_dgamma, void* stream) {
-  if (!d_z || !d_dy || !d_mean || !d_invstd || !d_gamma || !d_beta || !d_dz || !d_dbeta_dgamma)
+                           float* d_dbeta_dgamma, float* d_ws, void* stream) {
+  if (!d_z || !d_dy || !d_mean || !d_invstd || !d_gamma || !d_beta || !d_dz || !d_dbeta_dgamma || !d_ws)
     return set_err(M355_ERR_INVALID, "null pointer");
   const int rc = launch_bn_silu_train_bwd((const half_t*)d_z, (const half_t*)d_dy, (long)B * H * W, C, C, C, d_mean,
-                                          d_invstd, d_gamma, d_beta, d_dbeta_dgamma, (half_t*)d_dz, C, act,
+                                          d_invstd, d_gamma, d_beta, d_dbeta_dgamma, (half_t*)d_dz, C, act, d_ws,
                                           (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn bwd launch failed: " + std::to_string(rc));
 }
@@ -1508,7 +1520,9 @@ int m355_wgrad_launch(const m355_wgrad_args* w, void* stream) {
   if (!w || !w->dz || !w->x || !w->dw || !w->zero_page) return set_err(M355_ERR_INVALID, "null pointer");
   const int rc = launch_conv_wgrad((const half_t*)w->dz, w->dz_bstride, w->lddz, (const half_t*)w->x, w->x_bstride, w->ldx,
                                    w->batch, w->hi, w->wi, w->cin, w->ho, w->wo, w->cout, w->ksize, w->stride, w->pad,
-                                   w->dw, (const half_t*)w->zero_page, (hipStream_t)stream);
+                                   w->dw, (const half_t*)w->zero_page, w->ws, (size_t)(w->ws_bytes < 0 ? 0 : w->ws_bytes),
+                                   (hipStream_t)stream);
+  if (rc == -3) return set_err(M355_ERR_INVALID, "wgrad workspace missing or smaller than m355_wgrad_workspace_bytes()");
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "wgrad launch failed: " + std::to_string(rc));
 }
 
@@ -1525,10 +1539,10 @@ int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C
 
 int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_t ldz, int32_t lddy, int32_t C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t act,
-                             void* dz, int32_t lddz, float* dbeta_dgamma, void* stream) {
-  if (!z || !dy || !mean || !invstd || !gamma || !beta || !dz || !dbeta_dgamma) return set_err(M355_ERR_INVALID, "null pointer");
+                             void* dz, int32_t lddz, float* dbeta_dgamma, float* ws, void* stream) {
+  if (!z || !dy || !mean || !invstd || !gamma || !beta || !dz || !dbeta_dgamma || !ws) return set_err(M355_ERR_INVALID, "null pointer");
   const int rc = launch_bn_silu_train_bwd((const half_t*)z, (const half_t*)dy, npix, ldz, lddy, C, mean, invstd, gamma, beta,
-                                          dbeta_dgamma, (half_t*)dz, lddz, act, (hipStream_t)stream);
+                                          dbeta_dgamma, (half_t*)dz, lddz, act, ws, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn bwd launch failed: " + std::to_string(rc));
 }
 

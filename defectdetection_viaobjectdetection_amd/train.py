@@ -282,7 +282,7 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
     state1 = torch.zeros(n_train, device=dev)
     state2 = torch.zeros(n_train, device=dev)
     acc = torch.zeros(n_train, device=dev)
-    sumsq = torch.zeros(2, device=dev)
+    sumsq = torch.zeros(int(lib.m355_grad_sumsq_workspace_floats()), device=dev)   # [0] sum g^2, [1] non-finite count, then workspace
     reducer = GradBucketReducer(flat_g, eng.grad_spans(), bucket_bytes=int(a.bucket_mb) << 20) if world > 1 else None
 
     nb = len(epoch_batches(len(train_ds), local_batch, 0, a.seed, rank, world))
@@ -401,7 +401,7 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
                 reducer.finish()
             micro = 0
             check(lib.m355_grad_sumsq(flat_g.data_ptr(), n_train, sumsq.data_ptr(), st()))
-            ss, bad = sumsq.tolist()
+            ss, bad = sumsq[:2].tolist()
             found_inf = bad > 0 or not math.isfinite(ss)
             if not found_inf:
                 gnorm = math.sqrt(ss) / scaler.scale

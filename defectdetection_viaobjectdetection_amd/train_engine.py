@@ -58,6 +58,7 @@ class TrainEngine:
         self.saved: Dict[str, dict] = {}
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.dev)
         self.zero_bias = torch.zeros(4096, dtype=torch.float32, device=self.dev)
+        self.wgrad_ws = torch.empty(1 << 20, dtype=torch.float32, device=self.dev)   # split-K partial slabs (deterministic wgrad)
         self._build()
 
     # ------------------------------------------------------------------ graph
@@ -281,6 +282,10 @@ class TrainEngine:
         a.hi, a.wi, a.cin, a.ho, a.wo, a.cout = hi, wi, cin, ho, wo, cout
         a.ksize, a.stride, a.pad, a.batch = k, stride, pad, self.B
         a.dw, a.zero_page = dw.data_ptr(), self.zero_page.data_ptr()
+        need = int(lib.m355_wgrad_workspace_bytes(self.B, ho, wo, cin, cout, k))
+        if need > self.wgrad_ws.numel() * 4:                          # grows to the largest layer, then stays
+            self.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.dev)
+        a.ws, a.ws_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel() * 4
         check(lib.m355_wgrad_launch(C.byref(a), self._stream()))
 
     # ------------------------------------------------------------------ forward
@@ -305,7 +310,8 @@ class TrainEngine:
                     sv["z"] = torch.empty((B, ho, wo, cout), dtype=torch.float16, device=self.dev)
                     sv["mean"] = torch.empty(cout, device=self.dev)
                     sv["invstd"] = torch.empty(cout, device=self.dev)
-                    sv["ws"] = torch.empty(2 * cout, device=self.dev)
+                    # per-block partial sums + ticket of the ordered batch-norm reductions: zeroed once, self-resetting
+                    sv["ws"] = torch.zeros(int(lib.m355_bn_workspace_floats(cout)), device=self.dev)
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 self._conv_launch(xp, xbs, ldx, hi, wi, src.c, self.packed[name + ":fwd"], sv["z"].data_ptr(), ho * wo * cout,
                                   cout, ho, wo, cout, op["k"], op["s"], op["k"] // 2)
@@ -398,7 +404,7 @@ class TrainEngine:
                                                    sv["mean"].data_ptr(), sv["invstd"].data_ptr(),
                                                    self.params[f"{name}.bn.weight"].data_ptr(),
                                                    self.params[f"{name}.bn.bias"].data_ptr(), 1, sv["dz"].data_ptr(), cout,
-                                                   gb.data_ptr(), st))
+                                                   gb.data_ptr(), sv["ws"].data_ptr(), st))
                 ready += [f"{name}.bn.bias", f"{name}.bn.weight", f"{name}.conv.weight"]
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 gw = self.grads[f"{name}.conv.weight"]

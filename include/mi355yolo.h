@@ -139,18 +139,21 @@ int m355_conv2d_dgrad(const void* d_dy_f16_nhwc, int B, int H, int W, int cin, c
                       int stride, void* d_dx_f16_nhwc, void* stream);
 /* Weight gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2) (SURVEY A13 backward): X fp16 NHWC (B,H,W,cin),
  * dY fp16 NHWC (B,Ho,Wo,cout) -> dW fp32 DEVICE buffer in KRSC order (cout, k, k, cin) = the packed forward
- * weight order; zeroed and accumulated (split-K float atomics) by the call.                          [async] */
+ * weight order.  Deterministic: split-K partial slabs in a workspace the call allocates, added in split order. [sync] */
 int m355_conv2d_wgrad(const void* d_x_f16_nhwc, const void* d_dy_f16_nhwc, int B, int H, int W, int cin, int cout,
                       int k, int stride, float* d_dw_krsc, void* stream);
 /* Train-mode BatchNorm2d (batch statistics, biased variance, eps) + optional SiLU on fp16 NHWC (B,H,W,C)
  * (SURVEY A13): y = act(gamma * (z - mean) * invstd + beta).  gamma/beta/mean/invstd/ws are DEVICE fp32 arrays;
- * d_ws is a 2*C float workspace (sum, sum of squares); d_mean/d_invstd receive the saved statistics. */
+ * d_ws is a workspace of m355_bn_workspace_floats(C) floats that the caller zero-initialises ONCE (per-block partial sums
+ * + a ticket that returns to zero after every launch: the cross-block reduction runs in block order, no float atomics,
+ * bitwise reproducible); d_mean/d_invstd receive the saved statistics. */
+size_t m355_bn_workspace_floats(int C);
 int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const float* d_gamma, const float* d_beta,
                            float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream);
 /* Backward of the above: dz (fp16 NHWC) and d_dbeta_dgamma (device float[2*C]: [0:C] = dbeta, [C:2C] = dgamma). */
 int m355_bn_silu_train_bwd(const void* d_z, const void* d_dy, int B, int H, int W, int C, const float* d_mean,
                            const float* d_invstd, const float* d_gamma, const float* d_beta, int act, void* d_dz,
-                           float* d_dbeta_dgamma, void* stream);
+                           float* d_dbeta_dgamma, float* d_ws, void* stream);
 /* ConvTranspose2d(k=2,s=2)+bias; h_w fp32 (cin,cout,2,2).                                   [sync] */
 int m355_convt2x2_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, const float* h_w,
                       const float* h_bias, int cout, void* d_y_f16_nhwc, void* stream);
@@ -193,9 +196,13 @@ typedef struct {
   const void* x; int64_t x_bstride; int32_t ldx;      /* forward input slice, spatial hi x wi, cin channels */
   int32_t hi, wi, cin, ho, wo, cout;
   int32_t ksize, stride, pad, batch;
-  float* dw;                                          /* fp32 [cout][ksize*ksize*cin] (KRSC), zeroed by the call */
+  float* dw;                                          /* fp32 [cout][ksize*ksize*cin] (KRSC), overwritten */
   const void* zero_page;
+  float* ws; int64_t ws_bytes;                        /* >= m355_wgrad_workspace_bytes(...): split-K partial slabs */
 } m355_wgrad_args;
+/* Deterministic (no float atomics): every K split stores its partial tile to its slab of `ws`, a second kernel adds the
+ * slabs in split order.  M355_ERR_INVALID when ws is missing / too small for the shape. */
+size_t m355_wgrad_workspace_bytes(int32_t batch, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize);
 int m355_wgrad_launch(const m355_wgrad_args* a, void* stream);
 
 /* Train-mode BN(+SiLU)(+residual) on slices: y = act(bn(z)) + res.  running_mean / running_var (may be NULL) get the
@@ -206,7 +213,7 @@ int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C
                              void* stream);
 int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_t ldz, int32_t lddy, int32_t C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t act,
-                             void* dz, int32_t lddz, float* dbeta_dgamma, void* stream);
+                             void* dz, int32_t lddz, float* dbeta_dgamma, float* ws, void* stream);
 int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
@@ -221,7 +228,10 @@ int m355_adamw_step(float* p, const float* g, float* m, float* v, float* ema, co
 int m355_sgd_step(float* p, const float* g, float* momentum_buf, float* ema, const uint8_t* group, int64_t n, float lr,
                   float lr_bias, float momentum, int32_t nesterov, float weight_decay, float grad_mul, float ema_decay,
                   void* stream);
-/* out[0] = sum of squares of the finite entries of g, out[1] = number of non-finite entries (device floats). */
+/* out[0] = sum of squares of the finite entries of g, out[1] = number of non-finite entries.  `out` is a DEVICE buffer of
+ * m355_grad_sumsq_workspace_floats() floats, zero-initialised once by the caller (block partials + ticket behind the two
+ * results): fixed reduction order, bitwise reproducible. */
+size_t m355_grad_sumsq_workspace_floats(void);
 int m355_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
 
 /* Training-time augmentation on the device image cache (replaces upstream's CPU Mosaic / RandomPerspective /

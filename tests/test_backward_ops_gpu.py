@@ -69,15 +69,23 @@ def test_bn_silu_train_fwd_bwd(shape, act, cuda_device):
     d_y = torch.empty((B, H, W, Cc), dtype=torch.float16, device=dev)
     d_mean = torch.empty(Cc, device=dev)
     d_is = torch.empty(Cc, device=dev)
-    d_ws = torch.empty(2 * Cc, device=dev)
+    d_ws = torch.zeros(int(_capi.lib.m355_bn_workspace_floats(Cc)), device=dev)
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     _capi.check(_capi.lib.m355_bn_silu_train_fwd(_p(d_z), B, H, W, Cc, _p(d_g), _p(d_b), 1e-3, act, _p(d_y), _p(d_mean),
                                                  _p(d_is), _p(d_ws), st))
     d_dz = torch.empty_like(d_y)
     d_gb = torch.empty(2 * Cc, device=dev)
     _capi.check(_capi.lib.m355_bn_silu_train_bwd(_p(d_z), _p(d_dy), B, H, W, Cc, _p(d_mean), _p(d_is), _p(d_g), _p(d_b), act,
-                                                 _p(d_dz), _p(d_gb), st))
+                                                 _p(d_dz), _p(d_gb), _p(d_ws), st))
     torch.cuda.synchronize()
+    # ordered cross-block reductions (no float atomics): a second run gives the same bits
+    y1, dz1, gb1, m1 = d_y.clone(), d_dz.clone(), d_gb.clone(), d_mean.clone()
+    _capi.check(_capi.lib.m355_bn_silu_train_fwd(_p(d_z), B, H, W, Cc, _p(d_g), _p(d_b), 1e-3, act, _p(d_y), _p(d_mean),
+                                                 _p(d_is), _p(d_ws), st))
+    _capi.check(_capi.lib.m355_bn_silu_train_bwd(_p(d_z), _p(d_dy), B, H, W, Cc, _p(d_mean), _p(d_is), _p(d_g), _p(d_b), act,
+                                                 _p(d_dz), _p(d_gb), _p(d_ws), st))
+    torch.cuda.synchronize()
+    assert torch.equal(y1, d_y) and torch.equal(dz1, d_dz) and torch.equal(gb1, d_gb) and torch.equal(m1, d_mean)
     zd = z.detach()
     assert torch.allclose(d_mean.cpu(), zd.mean((0, 2, 3)), atol=1e-4)
     assert torch.allclose(d_is.cpu(), 1 / torch.sqrt(zd.var((0, 2, 3), unbiased=False) + 1e-3), rtol=1e-4)
@@ -118,3 +126,8 @@ def test_conv2d_wgrad(case, cuda_device):
     got = d_dw.cpu()
     assert torch.isfinite(got).all()
     assert rel_l2(got, ref) <= 1e-3
+    d_dw2 = torch.full_like(d_dw, float("nan"))                 # split-K slabs added in split order: the same bits again
+    _capi.check(_capi.lib.m355_conv2d_wgrad(_p(d_x), _p(d_dy), B, H, W, cin, cout, k, s, _p(d_dw2),
+                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(d_dw, d_dw2)

@@ -27,61 +27,99 @@ def _emulate_fp16_storage(oracle):
             m.register_forward_hook(rnd)
 
 
-@pytest.mark.parametrize("emulate", [False, True])
-@pytest.mark.parametrize("scale,shape,batch", [("n", (128, 160), 2), ("s", (96, 96), 3), ("n", (320, 320), 4)])
-def test_train_forward_backward_parity(scale, shape, batch, emulate, cuda_device):
+CASES = [("n", (128, 160), 2), ("s", (96, 96), 3), ("n", (320, 320), 4), ("m", (128, 160), 2), ("s", (320, 320), 4)]
+
+
+def _oracle_grads(scale, nc, sd, x, R1, R2, batch, emulate):
     import yolov8_seg_oracle as orc
+    oracle = orc.SegmentationModel(scale, nc)
+    oracle.load_state_dict(sd)
+    oracle.train()
+    if emulate:
+        _emulate_fp16_storage(oracle)
+    raw_l, mc, protos = oracle.forward_raw(x)
+    o_raw = torch.cat([r.view(batch, 64 + nc, -1) for r in raw_l], 2)
+    o_raw = torch.cat((o_raw, mc), 1).permute(0, 2, 1)                     # (B, A, 97)
+    loss = (o_raw * R1).sum() + (protos * R2).sum()
+    loss.backward()
+    return oracle, o_raw.detach(), protos.detach(), {k: v.grad for k, v in oracle.named_parameters()}
+
+
+@pytest.mark.parametrize("scale,shape,batch", CASES)
+def test_train_forward_backward_parity(scale, shape, batch, cuda_device):
+    """The HIP path against fp32 autograd, held to what fp16 STORAGE itself costs on the same batch: the oracle with its
+    conv / block outputs (and, through the same casts, their gradients) rounded to fp16 against the fp32 oracle.
+    A wrong backward formula anywhere shows up as an O(1) error / low cosine in every upstream tensor."""
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
     from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
     nc = 1
     sd = synthetic_state_dict(scale, nc, seed=3)
     eng = TrainEngine(scale, nc, shape, batch)
     eng.load_state_dict(sd)
-    oracle = orc.SegmentationModel(scale, nc)
-    oracle.load_state_dict(sd)
-    oracle.train()
-    if emulate:
-        _emulate_fp16_storage(oracle)
     imgs = synthetic_bscans(batch, shape[0], shape[1], seed=9)
     x = torch.from_numpy(imgs.transpose(0, 3, 1, 2).copy()).float() / 255.0
-    raw_l, mc, protos = oracle.forward_raw(x)
-    o_raw = torch.cat([r.view(batch, 64 + nc, -1) for r in raw_l], 2)
-    o_raw = torch.cat((o_raw, mc), 1).permute(0, 2, 1)                     # (B, A, 97)
+    A = sum((shape[0] // s) * (shape[1] // s) for s in (8, 16, 32))
     g = torch.Generator().manual_seed(1)
-    R1 = torch.randn(o_raw.shape, generator=g)
-    R2 = torch.randn(protos.shape, generator=g)                            # (B,32,h,w)
-    loss = (o_raw * R1).sum() + (protos * R2).sum()
-    loss.backward()
+    R1 = torch.randn((batch, A, 64 + nc + 32), generator=g)
+    R2 = torch.randn((batch, 32, shape[0] // 4, shape[1] // 4), generator=g)
+    oracle, o_raw, protos, g32 = _oracle_grads(scale, nc, sd, x, R1, R2, batch, False)
+    _, f_raw, f_protos, g16 = _oracle_grads(scale, nc, sd, x, R1, R2, batch, True)
 
     raw, pr = eng.forward(torch.from_numpy(imgs).to(cuda_device))
     torch.cuda.synchronize()
-    e_raw = rel_l2(raw.cpu(), o_raw.detach())
-    e_pr = rel_l2(pr.float().cpu().permute(0, 3, 1, 2), protos.detach())
-    print(f"forward: raw rel-L2 {e_raw:.2e}  protos rel-L2 {e_pr:.2e}")
+    e_raw = rel_l2(raw.cpu(), o_raw)
+    e_pr = rel_l2(pr.float().cpu().permute(0, 3, 1, 2), protos)
+    fl_raw, fl_pr = rel_l2(f_raw, o_raw), rel_l2(f_protos, protos)
+    print(f"forward: raw rel-L2 {e_raw:.2e} (format floor {fl_raw:.2e})  protos rel-L2 {e_pr:.2e} (floor {fl_pr:.2e})")
     # train-mode BN subtracts large post-SiLU channel means, which amplifies fp16 storage noise layer by layer
-    # (tools/debug_train_fwd.py: 5e-4 after the stem -> ~2e-2 at the heads, smooth, no jump at any op)
-    assert e_raw <= 4e-2 and e_pr <= 4e-2
+    assert e_raw <= 1.5 * fl_raw + 2e-3 and e_pr <= 1.5 * fl_pr + 2e-3
     S = 1.0   # loss scale: with these weights the gradients grow to ~5e2 towards the stem, well inside fp16 range
     eng.backward(R1.to(cuda_device) * S, R2.permute(0, 2, 3, 1).contiguous().to(cuda_device) * S)
     torch.cuda.synchronize()
-    osd = dict(oracle.named_parameters())
-    worst, cos = [], []
+    rows = []
     for name, p, gr in eng.trainable():
-        ref = osd[name].grad
+        ref = g32[name]
         got = gr.cpu() / S
         if got.dim() == 4 and not name.endswith("upsample.weight"):
             got = got.permute(0, 3, 1, 2)                                     # KRSC -> OIHW
         assert got.shape == ref.shape, name
         assert torch.isfinite(got).all(), name
-        worst.append((rel_l2(got, ref), name))
-        cos.append(float(torch.nn.functional.cosine_similarity(got.flatten(), ref.flatten(), dim=0)))
-    worst.sort(reverse=True)
-    print("worst parameter-gradient rel-L2:", [(f"{e:.2e}", n) for e, n in worst[:6]])
-    med = float(np.median([e for e, _ in worst]))
-    print(f"median {med:.2e} over {len(worst)} parameter tensors; min cosine {min(cos):.4f}")
-    # a wrong backward formula anywhere shows up as O(1) error / low cosine in every upstream tensor
-    # (the float atomics of the BN statistics / split-K wgrad make the result vary by ~1e-2 in cosine from run to run)
-    assert min(cos) >= 0.95 and worst[0][0] <= 0.32 and med <= 9e-2
+        cosf = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0))  # noqa: E731
+        rows.append((name, rel_l2(got, ref), rel_l2(g16[name], ref), cosf(got, ref), cosf(g16[name], ref)))
+    hip = np.array([r[1] for r in rows]); floor = np.array([r[2] for r in rows])
+    cos_h = np.array([r[3] for r in rows]); cos_f = np.array([r[4] for r in rows])
+    worst = sorted(rows, key=lambda r: -r[1])[:5]
+    print("worst parameter-gradient rel-L2 (HIP, floor):", [(n, f"{e:.2e}", f"{f:.2e}") for n, e, f, _, _ in worst])
+    print(f"{len(rows)} tensors: rel-L2 median HIP {np.median(hip):.2e} floor {np.median(floor):.2e}; max HIP {hip.max():.2e} floor {floor.max():.2e}; "
+          f"min cosine HIP {cos_h.min():.4f} floor {cos_f.min():.4f}")
+    # held to the format floor: the median (stable) x 1.5, every tensor x 2.5 of the larger of its own floor and the median
+    assert np.median(hip) <= 1.5 * np.median(floor) + 2e-3
+    assert (hip <= 2.5 * np.maximum(floor, np.median(floor)) + 5e-3).all(), [r for r in rows if r[1] > 2.5 * max(r[2], np.median(floor)) + 5e-3]
+    assert 1.0 - cos_h.min() <= 3.0 * (1.0 - cos_f.min()) + 1e-3
     # running statistics follow torch's momentum update
     rm = eng.params["model.0.bn.running_mean"].cpu()
     assert torch.allclose(rm, oracle.model[0].bn.running_mean, atol=2e-3)
+
+
+def test_forward_backward_is_bitwise_reproducible(cuda_device):
+    """No float atomics anywhere in the training kernels (ordered batch-norm reductions, split-K slabs added in split order):
+    the same batch gives the same bits, forward outputs and every parameter gradient."""
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
+    scale, shape, batch = "s", (160, 192), 4
+    eng = TrainEngine(scale, 1, shape, batch)
+    eng.load_state_dict(synthetic_state_dict(scale, 1, seed=3))
+    imgs = torch.from_numpy(synthetic_bscans(batch, shape[0], shape[1], seed=9)).to(cuda_device)
+    g = torch.Generator().manual_seed(1)
+    A = sum((shape[0] // s) * (shape[1] // s) for s in (8, 16, 32))
+    R1 = torch.randn((batch, A, 97), generator=g).to(cuda_device)
+    R2 = torch.randn((batch, shape[0] // 4, shape[1] // 4, 32), generator=g).to(cuda_device)
+    outs = []
+    for _ in range(3):
+        raw, pr = eng.forward(imgs, update_running_stats=False)
+        eng.backward(R1, R2)
+        torch.cuda.synchronize()
+        outs.append((raw.clone(), pr.clone(), eng.flat_grads.clone()))
+    for o in outs[1:]:
+        assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+        assert torch.equal(o[2], outs[0][2]), int((o[2] != outs[0][2]).sum())
