@@ -1,0 +1,140 @@
+"""Device-side parity of the training rows that run as torch ops on PyTorch-ROCm and of the validator (A17).
+
+A15: `loss.segmentation_loss` evaluated ON THE DEVICE -- on seeded head outputs and on the TrainEngine's own outputs --
+     against the training oracle on CPU copies of the same tensors: loss, its four items, gradients w.r.t. both inputs.
+A17: one trained checkpoint validated twice on the same images: through the HIP `Validator` (engine forward + HIP NMS +
+     HIP mask assembly + metrics.py) and through the oracle (fp32 forward + oracle NMS + oracle process_mask + the training
+     oracle's matcher / 101-point AP).  SURVEY 8d config 3: |delta mAP50| <= 0.002 (the metric's 0.2 points), box and mask.
+Reference call: /root/reference/BscanBased/yolo_seg_train.py:12-19 (train() validates every epoch)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import yolov8_seg_oracle as orc
+import yolov8_seg_train_oracle as tro
+from helpers import build_oracle, synthetic_bscans
+from test_loss_host import _case, _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,B,nc,imgsz,n_inst,empty", [(0, 8, 1, (320, 320), 3, False), (1, 4, 3, (160, 224), 2, True),
+                                                           (2, 16, 1, (160, 160), 1, False)])
+def test_loss_on_device_matches_oracle(seed, B, nc, imgsz, n_inst, empty, cuda_device):
+    from defectdetection_viaobjectdetection_amd import loss as L
+    raw, protos, batch, hw = _case(seed, B, nc, imgsz, n_inst, empty)
+    lo, io, gro, gpo = _oracle(raw, protos, batch, hw, nc, imgsz)
+    dev = cuda_device
+    r = raw.to(dev).requires_grad_(True)
+    p = protos.to(dev).requires_grad_(True)
+    dbatch = {k: v.to(dev) for k, v in batch.items()}
+    lp, ip = L.segmentation_loss(r, p, dbatch, nc, imgsz)
+    lp.backward()
+    torch.cuda.synchronize()
+    assert lp.device.type == "cuda" and r.grad.device.type == "cuda"
+    assert float(lp) == pytest.approx(float(lo), rel=2e-5)
+    np.testing.assert_allclose(ip.cpu().numpy(), io.numpy(), rtol=2e-5, atol=1e-6)
+    gr, gp = r.grad.cpu(), p.grad.cpu()
+    assert float((gr - gro).norm() / gro.norm()) <= 1e-5 and float((gp - gpo).norm() / gpo.norm()) <= 1e-5
+    np.testing.assert_allclose(gr.numpy(), gro.numpy(), rtol=2e-3, atol=2e-6)
+    np.testing.assert_allclose(gp.numpy(), gpo.numpy(), rtol=2e-3, atol=2e-6)
+
+
+def test_loss_on_the_train_engines_outputs(cuda_device):
+    """The same comparison on real head maps: TrainEngine.forward -> loss on the device tensors it returned."""
+    from defectdetection_viaobjectdetection_amd import loss as L
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
+    scale, nc, shape, B = "n", 1, (160, 192), 4
+    eng = TrainEngine(scale, nc, shape, B)
+    eng.load_state_dict(synthetic_state_dict(scale, nc, seed=3))
+    raw, protos = eng.forward(torch.from_numpy(synthetic_bscans(B, shape[0], shape[1], seed=9)).to(cuda_device))
+    _, _, batch, hw = _case(7, B, nc, shape, 2)
+    r = raw.detach().clone().requires_grad_(True)
+    p = protos.detach().float().requires_grad_(True)
+    lp, ip = L.segmentation_loss(r, p, {k: v.to(cuda_device) for k, v in batch.items()}, nc, shape)
+    lp.backward()
+    lo, io, gro, gpo = _oracle(raw.detach().cpu(), protos.detach().float().cpu(), batch, hw, nc, shape)
+    assert float(lp) == pytest.approx(float(lo), rel=2e-5)
+    np.testing.assert_allclose(ip.cpu().numpy(), io.numpy(), rtol=2e-5, atol=1e-6)
+    assert float((r.grad.cpu() - gro).norm() / gro.norm()) <= 1e-5 and float((p.grad.cpu() - gpo).norm() / gpo.norm()) <= 1e-5
+
+
+def _oracle_validation(model, sd, ds, conf=0.001, iou=0.7, max_det=300):
+    """fp32 oracle forward + oracle NMS + oracle process_mask + the training oracle's matcher and AP on dataset `ds`."""
+    from defectdetection_viaobjectdetection_amd.dataset import rasterize_polygon
+    oracle = build_oracle(model.scale, model.nc, sd)
+    H, W = ds.imgsz
+    tp_b, tp_m, confs, pcls, gcls = [], [], [], [], []
+    x = torch.from_numpy(ds.images.transpose(0, 3, 1, 2).copy()).float() / 255.0
+    with torch.no_grad():
+        preds, protos = oracle(x)
+    dets = orc.non_max_suppression(preds.numpy(), model.nc, conf, iou, max_det)
+    for i, d in enumerate(dets):
+        inst = ds.labels[i]
+        g_cls = np.array([c for c, _ in inst], np.int64)
+        g_box = np.array([[p[:, 0].min(), p[:, 1].min(), p[:, 0].max(), p[:, 1].max()] for _, p in inst], np.float64).reshape(-1, 4)
+        g_msk = np.stack([rasterize_polygon(p, H, W) for _, p in inst]) if inst else np.zeros((0, H, W), bool)
+        gcls.append(g_cls)
+        if d.shape[0] == 0:
+            continue
+        m = orc.process_mask(protos[i], torch.from_numpy(d[:, 6:]), torch.from_numpy(d[:, :4]), (H, W)).numpy().astype(bool)
+        b = d[:, :4].astype(np.float64)
+        ix1 = np.maximum(g_box[:, None, 0], b[None, :, 0]); iy1 = np.maximum(g_box[:, None, 1], b[None, :, 1])
+        ix2 = np.minimum(g_box[:, None, 2], b[None, :, 2]); iy2 = np.minimum(g_box[:, None, 3], b[None, :, 3])
+        inter = np.clip(ix2 - ix1, 0, None) * np.clip(iy2 - iy1, 0, None)
+        ag = (g_box[:, 2] - g_box[:, 0]) * (g_box[:, 3] - g_box[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+        iou_b = inter / (ag[:, None] + ab[None, :] - inter + 1e-7)
+        gm, pm = g_msk.reshape(len(g_msk), H * W).astype(np.float64), m.reshape(len(m), H * W).astype(np.float64)
+        im = gm @ pm.T
+        iou_m = im / (gm.sum(1)[:, None] + pm.sum(1)[None, :] - im + 1e-7)
+        c = d[:, 5].astype(np.int64)
+        tp_b.append(tro.match_predictions(c, g_cls, iou_b))
+        tp_m.append(tro.match_predictions(c, g_cls, iou_m))
+        confs.append(d[:, 4]); pcls.append(c)
+    gt_all = np.concatenate(gcls)
+    conf_all, cls_all = np.concatenate(confs), np.concatenate(pcls)
+    ap_b, _ = tro.ap_per_class(np.concatenate(tp_b), conf_all, cls_all, gt_all)
+    ap_m, _ = tro.ap_per_class(np.concatenate(tp_m), conf_all, cls_all, gt_all)
+    return {"mAP50(B)": float(ap_b[:, 0].mean()), "mAP50-95(B)": float(ap_b.mean()), "mAP50(M)": float(ap_m[:, 0].mean()),
+            "mAP50-95(M)": float(ap_m.mean()), "n_pred": int(conf_all.size)}
+
+
+def test_validator_map_matches_the_oracle_pipeline(tmp_path, cuda_device):
+    from ultralytics import YOLO
+    from defectdetection_viaobjectdetection_amd.dataset import SegDataset, read_data_yaml
+    from defectdetection_viaobjectdetection_amd.train import Validator
+    from test_train_api_gpu import make_defect_dataset
+    data = make_defect_dataset(str(tmp_path / "data-seg"), n_train=160, n_val=24, size=160, seed=5)
+    # the reference's own B-scans join the validation split (no defects labelled: they contribute false-positive pressure only)
+    golden = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    from PIL import Image
+    k = 0
+    for root_, _, files in os.walk(golden):
+        for f in sorted(files):
+            if f.endswith(".png") and k < 4:
+                Image.open(os.path.join(root_, f)).convert("RGB").resize((160, 160)).save(
+                    os.path.join(str(tmp_path / "data-seg"), "images", "val", f"fixture_{k}.png"))
+                open(os.path.join(str(tmp_path / "data-seg"), "labels", "val", f"fixture_{k}.txt"), "w").close()
+                k += 1
+    assert k == 4
+    model = YOLO("yolov8n-seg.yaml")
+    model.train(data=data, epochs=60, imgsz=160, batch=16, project=str(tmp_path / "runs"), name="v", device=0, warmup_epochs=1.0,
+                verbose=False)
+    best = YOLO(os.path.join(str(tmp_path / "runs"), "v", "weights", "best.pt"))
+    cfg = read_data_yaml(data)
+    ds = SegDataset(cfg["val"], 160, nc=1)
+    assert len(ds) == 28
+    v = Validator(ds, best.scale, best.nc, 0, batch=16)
+    hip = v(best.state_dict)
+    v.close()
+    ref = _oracle_validation(best, best.state_dict, ds)
+    print("HIP validator:", {k: round(val, 4) for k, val in hip.items() if "mAP" in k})
+    print("oracle pipeline:", {k: round(val, 4) if isinstance(val, float) else val for k, val in ref.items()})
+    assert ref["mAP50(B)"] > 0.3, "the checkpoint must have learnt something for the comparison to mean anything"
+    for key in ("mAP50(B)", "mAP50(M)"):
+        assert abs(hip[f"metrics/{key}"] - ref[key]) <= 0.002, (key, hip[f"metrics/{key}"], ref[key])
+    for key in ("mAP50-95(B)", "mAP50-95(M)"):
+        assert abs(hip[f"metrics/{key}"] - ref[key]) <= 0.005, (key, hip[f"metrics/{key}"], ref[key])
