@@ -120,8 +120,14 @@ class YOLO:
         self.ckpt_path = path
         self._resume_state = ck.get("trainer")       # present in weights/last.pt: lets train(resume=True) continue
 
-    def save(self, path: str) -> str:
+    def save(self, path: str, upstream: bool = False) -> str:
+        """``upstream=True`` writes upstream Ultralytics' own checkpoint layout (a pickled ``SegmentationModel`` module
+        graph, fp16, upstream_export.py) so that ``ultralytics.YOLO(path)`` of the real package can load it; the default
+        is this package's plain state-dict format."""
         os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+        if upstream:
+            from .upstream_export import export_upstream_checkpoint
+            return export_upstream_checkpoint(path, self.scale, self.nc, self.names, self.state_dict, self.train_args)
         torch.save({"format": CKPT_FORMAT, "scale": self.scale, "nc": self.nc, "names": self.names,
                     "train_args": self.train_args, "model": self.state_dict}, path)
         return path
