@@ -128,6 +128,9 @@ int launch_sppf_pool(const half_t* x, long x_bstride, int ldx, half_t* y, long y
                      int B, int H, int W, int C, hipStream_t s);
 int launch_upsample2x(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy,
                       int B, int H, int W, int C, hipStream_t s);
+// ADown's pooling (yolov9c): a = avg_pool2d(x, 2, 1, 0)[..., :C/2] (H-1 x W-1), m = max_pool2d(avg_pool2d(x, 2, 1, 0)[..., C/2:], 3, 2, 1) (H/2 x W/2)
+int launch_adown_pool(const half_t* x, long x_bstride, int ldx, half_t* a, long a_bstride, int lda, half_t* m, long m_bstride,
+                      int ldm, int B, int H, int W, int C, hipStream_t s);
 int launch_head_decode(const float* raw, int B, int in_h, int in_w, int nc, int nm, float* preds,
                        hipStream_t s);
 int launch_nms(const float* preds, int B, int A, int nc, int nm, float conf, float iou, int max_det,

@@ -39,13 +39,14 @@ struct ConvLayer {
   // fused group: logical convs that were merged into this physical conv (head first-layer fusion)
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_PHASE, OP_POOL, OP_UP, OP_DECODE };
+enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_PHASE, OP_POOL, OP_UP, OP_DECODE, OP_ADOWN };
 
 struct Op {
   OpKind kind;
   int conv = -1;       // physical conv index (phys_)
   Slice in, out, res;  // tensor slices
   Slice in2;           // upsample read-through: channels [0, in2.c) of `in` come from this half-resolution slice
+  Slice out2;          // OP_ADOWN: second output (max-pooled half); `out` is the average-pooled half
   int out_ext = 0;     // 0: internal tensor; 1: raw head buffer (fp32, anchor offset); 2: protos (caller)
   int raw_off = 0;     // channel offset in raw buffer
   int level_off = 0;   // anchor offset of the level in the raw buffer
@@ -241,8 +242,254 @@ struct Builder {
   }
 };
 
+// model.22 = Segment(nc, 32, npr) on the three feature tensors `feats` (channels fch): Detect branches, coefficient branch,
+// Proto, decode.  Shared by the yolov8-seg and yolov9c-seg graphs.
+int build_segment_head(m355_engine* e, Builder& b, const int feats[3], const int fch[3], const int npr) {
+  const int nc = e->nc, nm = e->nm;
+  const int H3 = e->tensors[feats[0]].H, W3 = e->tensors[feats[0]].W, H4 = e->tensors[feats[1]].H, W4 = e->tensors[feats[1]].W,
+            H5 = e->tensors[feats[2]].H, W5 = e->tensors[feats[2]].W, H2 = 2 * H3, W2 = 2 * W3;
+  const int hc2 = std::max(std::max(16, fch[0] / 4), 64);
+  const int hc3 = std::max(fch[0], std::min(nc, 100));
+  const int hc4 = std::max(fch[0] / 4, nm);
+  e->n3 = H3 * W3; e->n4 = H4 * W4; e->n5 = H5 * W5;
+  e->A = e->n3 + e->n4 + e->n5;
+  const int lvl_off[3] = {0, e->n3, e->n3 + e->n4};
+  // canonical logical order follows the upstream state dict: cv2.{l}.{0,1,2}, cv3.{l}.*, proto.*, cv4.{l}.*.
+  // Physical fusion: cv2.l.0 + cv3.l.0 + cv4.l.0 share their input -> one launch with cout = hc2+hc3+hc4.
+  int l_cv2[3][3], l_cv3[3][3], l_cv4[3][3];
+  for (int l = 0; l < 3; ++l) {
+    const std::string p = "model.22.cv2." + std::to_string(l);
+    l_cv2[l][0] = b.logical(p + ".0", fch[l], hc2, 3, 1, 1, 0, 1);
+    l_cv2[l][1] = b.logical(p + ".1", hc2, hc2, 3, 1, 1, 0, 1);
+    l_cv2[l][2] = b.logical(p + ".2", hc2, 64, 1, 1, 0, 0, 0);
+  }
+  for (int l = 0; l < 3; ++l) {
+    const std::string p = "model.22.cv3." + std::to_string(l);
+    l_cv3[l][0] = b.logical(p + ".0", fch[l], hc3, 3, 1, 1, 0, 1);
+    l_cv3[l][1] = b.logical(p + ".1", hc3, hc3, 3, 1, 1, 0, 1);
+    l_cv3[l][2] = b.logical(p + ".2", hc3, nc, 1, 1, 0, 0, 0);
+  }
+  const int l_p1 = b.logical("model.22.proto.cv1", fch[0], npr, 3, 1, 1, 0, 1);
+  const int l_pu = b.logical("model.22.proto.upsample", npr, npr, 2, 2, 0, 1, 0);
+  const int l_p2 = b.logical("model.22.proto.cv2", npr, npr, 3, 1, 1, 0, 1);
+  const int l_p3 = b.logical("model.22.proto.cv3", npr, nm, 1, 1, 1, 0, 1);
+  for (int l = 0; l < 3; ++l) {
+    const std::string p = "model.22.cv4." + std::to_string(l);
+    l_cv4[l][0] = b.logical(p + ".0", fch[l], hc4, 3, 1, 1, 0, 1);
+    l_cv4[l][1] = b.logical(p + ".1", hc4, hc4, 3, 1, 1, 0, 1);
+    l_cv4[l][2] = b.logical(p + ".2", hc4, nm, 1, 1, 0, 0, 0);
+  }
+  auto add_conv_op = [&](const std::vector<int>& logicals, Slice in, Slice out, int out_ext, int raw_off,
+                         int level_off, OpKind kind = OP_CONV) {
+    Op op{};
+    op.kind = kind;
+    op.conv = b.phys_from(logicals);
+    op.in = in; op.out = out; op.out_ext = out_ext; op.raw_off = raw_off; op.level_off = level_off;
+    b.add_macs(op, e->phys[op.conv]);
+    e->ops.push_back(op);
+  };
+  const int HW[3][2] = {{H3, W3}, {H4, W4}, {H5, W5}};
+  // stream lane of Proto and of the three head levels (plan_lanes): measured best on MI355X at batch 32
+  int lane_plan[4] = {1, 2, 2, 0};
+  if (const char* lp = getenv("M355_LANE_PLAN"))
+    for (int i = 0; i < 4 && lp[i] >= '0' && lp[i] <= '3'; ++i) lane_plan[i] = lp[i] - '0';
+  for (int l = 0; l < 3; ++l) {
+    const size_t lvl_first = e->ops.size();
+    const int hcat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
+    const Slice f{feats[l], 0, fch[l]};
+    add_conv_op({l_cv2[l][0], l_cv3[l][0], l_cv4[l][0]}, f, Slice{hcat, 0, hc2 + hc3 + hc4}, 0, 0, 0);
+    // the three second convs write side by side into one tensor, so that the three 1x1 output convs (64 box bins,
+    // nc classes, nm mask coefficients: different inputs) run as ONE launch with a block-diagonal weight matrix and
+    // write a whole row of the raw head map
+    const int ucat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
+    add_conv_op({l_cv2[l][1]}, Slice{hcat, 0, hc2}, Slice{ucat, 0, hc2}, 0, 0, 0);
+    add_conv_op({l_cv3[l][1]}, Slice{hcat, hc2, hc3}, Slice{ucat, hc2, hc3}, 0, 0, 0);
+    add_conv_op({l_cv4[l][1]}, Slice{hcat, hc2 + hc3, hc4}, Slice{ucat, hc2 + hc3, hc4}, 0, 0, 0);
+    {
+      Op op{};
+      op.kind = OP_CONV;
+      op.conv = b.phys_diag({l_cv2[l][2], l_cv3[l][2], l_cv4[l][2]});
+      op.in = Slice{ucat, 0, hc2 + hc3 + hc4};
+      op.out = Slice{-1, 0, 64 + nc + nm};
+      op.out_ext = 1; op.raw_off = 0; op.level_off = lvl_off[l];
+      b.add_macs(op, e->phys[op.conv]);
+      e->ops.push_back(op);
+    }
+    for (size_t i = lvl_first; i < e->ops.size(); ++i) e->ops[i].lane = lane_plan[1 + l];
+  }
+  const size_t proto_first = e->ops.size();
+  {
+    const bool fuse2 = !getenv("M355_NO_PROTOFUSE") && npr % 64 == 0;   // a channel tile (64 or 128) must lie inside one phase
+    const bool fuse3 = fuse2 && npr == 128 && nm == 32 && !getenv("M355_NO_PROTOFUSE3");
+    const int pr1 = b.tensor(H3, W3, npr);
+    add_conv_op({l_p1}, Slice{feats[0], 0, fch[0]}, Slice{pr1, 0, npr}, 0, 0, 0);
+    if (!fuse2) {
+      const int pr2 = b.tensor(H2, W2, npr), pr3 = b.tensor(H2, W2, npr);
+      add_conv_op({l_pu}, Slice{pr1, 0, npr}, Slice{pr2, 0, npr}, 0, 0, 0, OP_CONVT);
+      add_conv_op({l_p2}, Slice{pr2, 0, npr}, Slice{pr3, 0, npr}, 0, 0, 0);
+      add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
+    } else {
+      // ConvTranspose2d(2x2, s2, bias) has no activation, so upsample -> cv2's 3x3 conv is ONE linear map of the
+      // 80x80 tensor: per output phase (py, px) a 2x2 convolution with composed weights (host, fp64).  4 taps instead
+      // of 1 + 9 per output pixel, and the 160x160x128 intermediate (0.42 GB of HBM traffic at batch 32) is gone.
+      // With 128 prototype channels a 128 x 128 tile holds every channel of its pixels, so proto.cv3 (1x1, 128 -> 32)
+      // runs in the same kernel's epilogue and the 160x160x128 tensor is never written at all.
+      Op op{};
+      op.kind = OP_PHASE;
+      PhysConv p;
+      p.logical = {l_pu, l_p2};
+      p.cin = npr; p.cout = npr; p.k = 2; p.stride = 1; p.act = 1; p.composed = 1;
+      p.macs_px = 4.0 * (4.0 * npr) * npr;      // per LOW-resolution pixel: 4 phases x 4 taps x npr x npr
+      if (fuse3) {
+        p.logical.push_back(l_p3);
+        p.l3 = l_p3;
+        p.cout2 = nm;
+        p.macs_px += 4.0 * npr * nm;
+        e->conv_phys[l_p3] = (int)e->phys.size();
+      }
+      e->conv_phys[l_pu] = e->conv_phys[l_p2] = (int)e->phys.size();
+      e->phys.push_back(p);
+      op.conv = (int)e->phys.size() - 1;
+      op.in = Slice{pr1, 0, npr};
+      // the model's nominal MACs (upstream counts ConvT + 3x3 (+ 1x1)) stay in the whole-net figure
+      e->macs += (double)(2 * H3) * (2 * W3) * npr * npr + (double)(2 * H3) * (2 * W3) * npr * npr * 9;
+      if (fuse3) {
+        op.out = Slice{-1, 0, nm};
+        op.out_ext = 2;
+        e->macs += (double)(2 * H3) * (2 * W3) * npr * nm;
+        e->ops.push_back(op);
+      } else {
+        const int pr3 = b.tensor(H2, W2, npr);
+        op.out = Slice{pr3, 0, npr};
+        e->ops.push_back(op);
+        add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
+      }
+    }
+  }
+  for (size_t i = proto_first; i < e->ops.size(); ++i) e->ops[i].lane = lane_plan[0];
+  {
+    Op op{};
+    op.kind = OP_DECODE;
+    e->ops.push_back(op);
+  }
+  e->proto_h = H2; e->proto_w = W2;
+  return 0;
+}
+
+// yolov9c-seg (SURVEY next row N4: the architecture /root/reference/BscanBased/yolo_seg_train.py:7 names).  GELAN blocks on
+// the same conv kernels: RepNCSPELAN4 = 1x1 -> two (RepCSP -> 3x3) stages -> 1x1 over the zero-copy concat of all four
+// parts; RepCSP = two 1x1 branches, one RepBottleneck (RepConvN arrives from the host as ONE merged 3x3 conv), 1x1;
+// ADown = one pooling kernel (2x2 average, then 3x3 / s2 max on the second channel half) + a 3x3 / s2 and a 1x1 conv
+// writing the two halves of the output; SPPELAN = SPPF's serial pooling between two 1x1 convs.
+// Block structure and names: oracle/yolov9c_seg_oracle.py (exact published parameter counts), spec.py conv_specs_v9c.
+struct V9cBuilder {
+  m355_engine* e;
+  Builder& b;
+  // RepCSP(c1 -> c2) from slice `in` to slice `out`
+  void repcsp(const std::string& name, Slice in, Slice out) {
+    const Tensor& ti = e->tensors[in.t];
+    const int c_ = out.c / 2;
+    const int tmp = b.tensor(ti.H, ti.W, c_), mid = b.tensor(ti.H, ti.W, c_), cat = b.tensor(ti.H, ti.W, 2 * c_);
+    b.conv(name + ".cv1", in, Slice{tmp, 0, c_}, 1, 1);
+    b.conv(name + ".m.0.cv1", Slice{tmp, 0, c_}, Slice{mid, 0, c_}, 3, 1);                        // RepConvN, merged
+    b.conv(name + ".m.0.cv2", Slice{mid, 0, c_}, Slice{cat, 0, c_}, 3, 1, Slice{tmp, 0, c_});     // + shortcut
+    b.conv(name + ".cv2", in, Slice{cat, c_, c_}, 1, 1);
+    b.conv(name + ".cv3", Slice{cat, 0, 2 * c_}, out, 1, 1);
+  }
+  void elan(const std::string& name, Slice in, Slice out, int c3, int c4, Slice up_src = Slice()) {
+    const Tensor& ti = e->tensors[in.t];
+    const int cat = b.tensor(ti.H, ti.W, c3 + 2 * c4);
+    b.conv(name + ".cv1", in, Slice{cat, 0, c3}, 1, 1, Slice(), up_src);
+    const int r1 = b.tensor(ti.H, ti.W, c4), r2 = b.tensor(ti.H, ti.W, c4);
+    repcsp(name + ".cv2.0", Slice{cat, c3 / 2, c3 / 2}, Slice{r1, 0, c4});
+    b.conv(name + ".cv2.1", Slice{r1, 0, c4}, Slice{cat, c3, c4}, 3, 1);
+    repcsp(name + ".cv3.0", Slice{cat, c3, c4}, Slice{r2, 0, c4});
+    b.conv(name + ".cv3.1", Slice{r2, 0, c4}, Slice{cat, c3 + c4, c4}, 3, 1);
+    b.conv(name + ".cv4", Slice{cat, 0, c3 + 2 * c4}, out, 1, 1);
+  }
+  void adown(const std::string& name, Slice in, Slice out) {
+    const Tensor& ti = e->tensors[in.t];
+    const int ch = in.c / 2, co = out.c / 2;
+    const int ta = b.tensor(ti.H - 1, ti.W - 1, ch), tm = b.tensor(ti.H / 2, ti.W / 2, ch);
+    Op op{};
+    op.kind = OP_ADOWN;
+    op.in = in; op.out = Slice{ta, 0, ch}; op.out2 = Slice{tm, 0, ch};
+    e->ops.push_back(op);
+    b.conv(name + ".cv1", Slice{ta, 0, ch}, Slice{out.t, out.off, co}, 3, 2);
+    b.conv(name + ".cv2", Slice{tm, 0, ch}, Slice{out.t, out.off + co, co}, 1, 1);
+  }
+};
+
+int build_graph_v9c(m355_engine* e) {
+  const m355_model_desc& d = e->desc;
+  Builder b{e, 1.0, 1.0, 1024};
+  V9cBuilder v{e, b};
+  if (d.in_h % 32 || d.in_w % 32 || d.in_h < 64 || d.in_w < 64)
+    return e->fail(M355_ERR_INVALID, "in_h/in_w must be multiples of 32, at least 64");
+  if (d.nc < 1 || d.max_batch < 1) return e->fail(M355_ERR_INVALID, "nc and max_batch must be >= 1");
+  e->nc = d.nc; e->nm = 32;
+  const int H = d.in_h, W = d.in_w;
+  const int H1 = H / 2, W1 = W / 2, H2 = H / 4, W2 = W / 4, H3 = H / 8, W3 = W / 8, H4 = H / 16, W4 = W / 16, H5 = H / 32, W5 = W / 32;
+  // zero-copy concat buffers: cat11 = [up(x9), x6], cat14 = [up(x12), x4], cat17 = [x16, x12], cat20 = [x19, x9]
+  const int cat11 = b.tensor(H4, W4, 512 + 512), cat14 = b.tensor(H3, W3, 512 + 512);
+  const int cat17 = b.tensor(H4, W4, 256 + 512), cat20 = b.tensor(H5, W5, 512 + 512);
+  const Slice x4{cat14, 512, 512}, x6{cat11, 512, 512}, x9{cat20, 512, 512}, x12{cat17, 256, 512};
+  const int t0 = b.tensor(H1, W1, 64);
+  {
+    const int li = b.logical("model.0", 3, 64, 3, 2, 1, 0, 1);
+    Op op{};
+    op.kind = OP_STEM;
+    op.conv = b.phys_from({li});
+    op.out = Slice{t0, 0, 64};
+    op.Hi = H; op.Wi = W;
+    e->macs += (double)H1 * W1 * 64 * 27;
+    e->ops.push_back(op);
+  }
+  const int t1 = b.tensor(H2, W2, 128), t2 = b.tensor(H2, W2, 256), t3 = b.tensor(H3, W3, 256), t5 = b.tensor(H4, W4, 512),
+            t7 = b.tensor(H5, W5, 512), t8 = b.tensor(H5, W5, 512);
+  b.conv("model.1", Slice{t0, 0, 64}, Slice{t1, 0, 128}, 3, 2);
+  v.elan("model.2", Slice{t1, 0, 128}, Slice{t2, 0, 256}, 128, 64);
+  v.adown("model.3", Slice{t2, 0, 256}, Slice{t3, 0, 256});
+  v.elan("model.4", Slice{t3, 0, 256}, x4, 256, 128);
+  v.adown("model.5", x4, Slice{t5, 0, 512});
+  v.elan("model.6", Slice{t5, 0, 512}, x6, 512, 256);
+  v.adown("model.7", x6, Slice{t7, 0, 512});
+  v.elan("model.8", Slice{t7, 0, 512}, Slice{t8, 0, 512}, 512, 256);
+  {
+    const int sp = b.tensor(H5, W5, 4 * 256);                  // SPPELAN: cv1 -> three serial 5x5 max pools -> cv5
+    b.conv("model.9.cv1", Slice{t8, 0, 512}, Slice{sp, 0, 256}, 1, 1);
+    Op op{};
+    op.kind = OP_POOL;
+    op.in = Slice{sp, 0, 256};
+    op.out = Slice{sp, 256, 3 * 256};
+    e->ops.push_back(op);
+    b.conv("model.9.cv5", Slice{sp, 0, 1024}, x9, 1, 1);
+  }
+  const bool upfuse = !getenv("M355_NO_UPFUSE");
+  auto up = [&](Slice src, Slice dst) {
+    if (upfuse) return;
+    Op op{};
+    op.kind = OP_UP;
+    op.in = src; op.out = dst;
+    e->ops.push_back(op);
+  };
+  up(x9, Slice{cat11, 0, 512});
+  v.elan("model.12", Slice{cat11, 0, 1024}, x12, 512, 256, upfuse ? x9 : Slice());
+  up(x12, Slice{cat14, 0, 512});
+  const int t15 = b.tensor(H3, W3, 256), t18 = b.tensor(H4, W4, 512), t21 = b.tensor(H5, W5, 512);
+  v.elan("model.15", Slice{cat14, 0, 1024}, Slice{t15, 0, 256}, 256, 128, upfuse ? x12 : Slice());
+  v.adown("model.16", Slice{t15, 0, 256}, Slice{cat17, 0, 256});
+  v.elan("model.18", Slice{cat17, 0, 768}, Slice{t18, 0, 512}, 512, 256);
+  v.adown("model.19", Slice{t18, 0, 512}, Slice{cat20, 0, 512});
+  v.elan("model.21", Slice{cat20, 0, 1024}, Slice{t21, 0, 512}, 512, 256);
+  const int feats[3] = {t15, t18, t21};
+  const int fch[3] = {256, 512, 512};
+  return build_segment_head(e, b, feats, fch, 256);
+}
+
 int build_graph(m355_engine* e) {
   const m355_model_desc& d = e->desc;
+  if (d.scale == 'c') return build_graph_v9c(e);
   Builder b{e, 0, 0, 0};
   switch (d.scale) {
     case 'n': b.depth = 0.33; b.width = 0.25; b.maxc = 1024; break;
@@ -250,7 +497,7 @@ int build_graph(m355_engine* e) {
     case 'm': b.depth = 0.67; b.width = 0.75; b.maxc = 768; break;
     case 'l': b.depth = 1.00; b.width = 1.00; b.maxc = 512; break;
     case 'x': b.depth = 1.00; b.width = 1.25; b.maxc = 512; break;
-    default: return e->fail(M355_ERR_INVALID, "scale must be one of n,s,m,l,x");
+    default: return e->fail(M355_ERR_INVALID, "scale must be one of n,s,m,l,x (yolov8-seg) or c (yolov9c-seg)");
   }
   if (d.in_h % 32 || d.in_w % 32 || d.in_h < 32 || d.in_w < 32)
     return e->fail(M355_ERR_INVALID, "in_h/in_w must be positive multiples of 32");
@@ -340,133 +587,7 @@ int build_graph(m355_engine* e) {
   // 22: Segment head
   const int feats[3] = {t15, t18, t21};
   const int fch[3] = {c256, c512, c1024};
-  const int hc2 = std::max(std::max(16, fch[0] / 4), 64);
-  const int hc3 = std::max(fch[0], std::min(nc, 100));
-  const int hc4 = std::max(fch[0] / 4, nm);
-  const int npr = b.ch(256);
-  e->n3 = H3 * W3; e->n4 = H4 * W4; e->n5 = H5 * W5;
-  e->A = e->n3 + e->n4 + e->n5;
-  const int lvl_off[3] = {0, e->n3, e->n3 + e->n4};
-  // canonical logical order follows the upstream state dict: cv2.{l}.{0,1,2}, cv3.{l}.*, proto.*, cv4.{l}.*.
-  // Physical fusion: cv2.l.0 + cv3.l.0 + cv4.l.0 share their input -> one launch with cout = hc2+hc3+hc4.
-  int l_cv2[3][3], l_cv3[3][3], l_cv4[3][3];
-  for (int l = 0; l < 3; ++l) {
-    const std::string p = "model.22.cv2." + std::to_string(l);
-    l_cv2[l][0] = b.logical(p + ".0", fch[l], hc2, 3, 1, 1, 0, 1);
-    l_cv2[l][1] = b.logical(p + ".1", hc2, hc2, 3, 1, 1, 0, 1);
-    l_cv2[l][2] = b.logical(p + ".2", hc2, 64, 1, 1, 0, 0, 0);
-  }
-  for (int l = 0; l < 3; ++l) {
-    const std::string p = "model.22.cv3." + std::to_string(l);
-    l_cv3[l][0] = b.logical(p + ".0", fch[l], hc3, 3, 1, 1, 0, 1);
-    l_cv3[l][1] = b.logical(p + ".1", hc3, hc3, 3, 1, 1, 0, 1);
-    l_cv3[l][2] = b.logical(p + ".2", hc3, nc, 1, 1, 0, 0, 0);
-  }
-  const int l_p1 = b.logical("model.22.proto.cv1", fch[0], npr, 3, 1, 1, 0, 1);
-  const int l_pu = b.logical("model.22.proto.upsample", npr, npr, 2, 2, 0, 1, 0);
-  const int l_p2 = b.logical("model.22.proto.cv2", npr, npr, 3, 1, 1, 0, 1);
-  const int l_p3 = b.logical("model.22.proto.cv3", npr, nm, 1, 1, 1, 0, 1);
-  for (int l = 0; l < 3; ++l) {
-    const std::string p = "model.22.cv4." + std::to_string(l);
-    l_cv4[l][0] = b.logical(p + ".0", fch[l], hc4, 3, 1, 1, 0, 1);
-    l_cv4[l][1] = b.logical(p + ".1", hc4, hc4, 3, 1, 1, 0, 1);
-    l_cv4[l][2] = b.logical(p + ".2", hc4, nm, 1, 1, 0, 0, 0);
-  }
-  auto add_conv_op = [&](const std::vector<int>& logicals, Slice in, Slice out, int out_ext, int raw_off,
-                         int level_off, OpKind kind = OP_CONV) {
-    Op op{};
-    op.kind = kind;
-    op.conv = b.phys_from(logicals);
-    op.in = in; op.out = out; op.out_ext = out_ext; op.raw_off = raw_off; op.level_off = level_off;
-    b.add_macs(op, e->phys[op.conv]);
-    e->ops.push_back(op);
-  };
-  const int HW[3][2] = {{H3, W3}, {H4, W4}, {H5, W5}};
-  // stream lane of Proto and of the three head levels (plan_lanes): measured best on MI355X at batch 32
-  int lane_plan[4] = {1, 2, 2, 0};
-  if (const char* lp = getenv("M355_LANE_PLAN"))
-    for (int i = 0; i < 4 && lp[i] >= '0' && lp[i] <= '3'; ++i) lane_plan[i] = lp[i] - '0';
-  for (int l = 0; l < 3; ++l) {
-    const size_t lvl_first = e->ops.size();
-    const int hcat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
-    const Slice f{feats[l], 0, fch[l]};
-    add_conv_op({l_cv2[l][0], l_cv3[l][0], l_cv4[l][0]}, f, Slice{hcat, 0, hc2 + hc3 + hc4}, 0, 0, 0);
-    // the three second convs write side by side into one tensor, so that the three 1x1 output convs (64 box bins,
-    // nc classes, nm mask coefficients: different inputs) run as ONE launch with a block-diagonal weight matrix and
-    // write a whole row of the raw head map
-    const int ucat = b.tensor(HW[l][0], HW[l][1], hc2 + hc3 + hc4);
-    add_conv_op({l_cv2[l][1]}, Slice{hcat, 0, hc2}, Slice{ucat, 0, hc2}, 0, 0, 0);
-    add_conv_op({l_cv3[l][1]}, Slice{hcat, hc2, hc3}, Slice{ucat, hc2, hc3}, 0, 0, 0);
-    add_conv_op({l_cv4[l][1]}, Slice{hcat, hc2 + hc3, hc4}, Slice{ucat, hc2 + hc3, hc4}, 0, 0, 0);
-    {
-      Op op{};
-      op.kind = OP_CONV;
-      op.conv = b.phys_diag({l_cv2[l][2], l_cv3[l][2], l_cv4[l][2]});
-      op.in = Slice{ucat, 0, hc2 + hc3 + hc4};
-      op.out = Slice{-1, 0, 64 + nc + nm};
-      op.out_ext = 1; op.raw_off = 0; op.level_off = lvl_off[l];
-      b.add_macs(op, e->phys[op.conv]);
-      e->ops.push_back(op);
-    }
-    for (size_t i = lvl_first; i < e->ops.size(); ++i) e->ops[i].lane = lane_plan[1 + l];
-  }
-  const size_t proto_first = e->ops.size();
-  {
-    const bool fuse2 = !getenv("M355_NO_PROTOFUSE") && npr % 64 == 0;   // a channel tile (64 or 128) must lie inside one phase
-    const bool fuse3 = fuse2 && npr == 128 && nm == 32 && !getenv("M355_NO_PROTOFUSE3");
-    const int pr1 = b.tensor(H3, W3, npr);
-    add_conv_op({l_p1}, Slice{t15, 0, c256}, Slice{pr1, 0, npr}, 0, 0, 0);
-    if (!fuse2) {
-      const int pr2 = b.tensor(H2, W2, npr), pr3 = b.tensor(H2, W2, npr);
-      add_conv_op({l_pu}, Slice{pr1, 0, npr}, Slice{pr2, 0, npr}, 0, 0, 0, OP_CONVT);
-      add_conv_op({l_p2}, Slice{pr2, 0, npr}, Slice{pr3, 0, npr}, 0, 0, 0);
-      add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
-    } else {
-      // ConvTranspose2d(2x2, s2, bias) has no activation, so upsample -> cv2's 3x3 conv is ONE linear map of the
-      // 80x80 tensor: per output phase (py, px) a 2x2 convolution with composed weights (host, fp64).  4 taps instead
-      // of 1 + 9 per output pixel, and the 160x160x128 intermediate (0.42 GB of HBM traffic at batch 32) is gone.
-      // With 128 prototype channels a 128 x 128 tile holds every channel of its pixels, so proto.cv3 (1x1, 128 -> 32)
-      // runs in the same kernel's epilogue and the 160x160x128 tensor is never written at all.
-      Op op{};
-      op.kind = OP_PHASE;
-      PhysConv p;
-      p.logical = {l_pu, l_p2};
-      p.cin = npr; p.cout = npr; p.k = 2; p.stride = 1; p.act = 1; p.composed = 1;
-      p.macs_px = 4.0 * (4.0 * npr) * npr;      // per LOW-resolution pixel: 4 phases x 4 taps x npr x npr
-      if (fuse3) {
-        p.logical.push_back(l_p3);
-        p.l3 = l_p3;
-        p.cout2 = nm;
-        p.macs_px += 4.0 * npr * nm;
-        e->conv_phys[l_p3] = (int)e->phys.size();
-      }
-      e->conv_phys[l_pu] = e->conv_phys[l_p2] = (int)e->phys.size();
-      e->phys.push_back(p);
-      op.conv = (int)e->phys.size() - 1;
-      op.in = Slice{pr1, 0, npr};
-      // the model's nominal MACs (upstream counts ConvT + 3x3 (+ 1x1)) stay in the whole-net figure
-      e->macs += (double)(2 * H3) * (2 * W3) * npr * npr + (double)(2 * H3) * (2 * W3) * npr * npr * 9;
-      if (fuse3) {
-        op.out = Slice{-1, 0, nm};
-        op.out_ext = 2;
-        e->macs += (double)(2 * H3) * (2 * W3) * npr * nm;
-        e->ops.push_back(op);
-      } else {
-        const int pr3 = b.tensor(H2, W2, npr);
-        op.out = Slice{pr3, 0, npr};
-        e->ops.push_back(op);
-        add_conv_op({l_p3}, Slice{pr3, 0, npr}, Slice{-1, 0, nm}, 2, 0, 0);
-      }
-    }
-  }
-  for (size_t i = proto_first; i < e->ops.size(); ++i) e->ops[i].lane = lane_plan[0];
-  {
-    Op op{};
-    op.kind = OP_DECODE;
-    e->ops.push_back(op);
-  }
-  e->proto_h = H2; e->proto_w = W2;
-  return 0;
+  return build_segment_head(e, b, feats, fch, b.ch(256));
 }
 
 // A stride-2 backbone conv whose ONLY consumer is the 1x1 cv1 of the following C2f, with as many channels as one
@@ -539,7 +660,8 @@ std::vector<int> op_producers(const m355_engine* e, int i) {
       continue;
     }
     if (q.out_ext != 0 || q.out.t < 0) continue;
-    if (q.out.t == op.in.t || (op.in2.t >= 0 && q.out.t == op.in2.t) || (op.res.t >= 0 && q.out.t == op.res.t)) r.push_back(j);
+    auto reads = [&](int t) { return t == op.in.t || (op.in2.t >= 0 && t == op.in2.t) || (op.res.t >= 0 && t == op.res.t); };
+    if (reads(q.out.t) || (q.kind == OP_ADOWN && reads(q.out2.t))) r.push_back(j);
   }
   return r;
 }
@@ -766,6 +888,13 @@ void annotate_ops(m355_engine* e) {
         snprintf(op.kernel, sizeof(op.kernel), "sppf_pool");
         snprintf(op.layer, sizeof(op.layer), "model.9.m");
         op.bytes = (double)t.H * t.W * op.in.c * 2 * 4;
+        break;
+      }
+      case OP_ADOWN: {
+        const Tensor& t = e->tensors[op.in.t];
+        snprintf(op.kernel, sizeof(op.kernel), "adown_pool");
+        snprintf(op.layer, sizeof(op.layer), "adown.pool");
+        op.bytes = (double)t.H * t.W * op.in.c * 2 + (double)(t.H - 1) * (t.W - 1) * op.out.c * 2 + (double)(t.H / 2) * (t.W / 2) * op.out2.c * 2;
         break;
       }
       case OP_UP: {
@@ -1105,6 +1234,14 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         const Tensor& t = e->tensors[op.in.t];
         rc = launch_sppf_pool(t.p + op.in.off, (long)t.H * t.W * t.C, t.C, t.p + op.out.off, (long)t.H * t.W * t.C,
                               t.C, Bq, t.H, t.W, op.in.c, s);
+        break;
+      }
+      case OP_ADOWN: {
+        const Tensor& ti = e->tensors[op.in.t];
+        const Tensor& ta = e->tensors[op.out.t];
+        const Tensor& tm = e->tensors[op.out2.t];
+        rc = launch_adown_pool(ti.p + op.in.off, (long)ti.H * ti.W * ti.C, ti.C, ta.p + op.out.off, (long)ta.H * ta.W * ta.C, ta.C,
+                               tm.p + op.out2.off, (long)tm.H * tm.W * tm.C, tm.C, Bq, ti.H, ti.W, op.in.c, s);
         break;
       }
       case OP_UP: {

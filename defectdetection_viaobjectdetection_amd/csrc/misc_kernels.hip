@@ -412,4 +412,80 @@ int launch_head_decode(const float* raw, int B, int in_h, int in_w, int nc, int 
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// ADown's pooling front (yolov9c-seg, SURVEY next row N4; upstream reaches it through F.avg_pool2d / F.max_pool2d):
+//   x' = avg_pool2d(x, 2, 1, 0)                          (H-1) x (W-1)
+//   a  = x'[..., :C/2]                                   input of the 3x3 / s2 conv
+//   m  = max_pool2d(x'[..., C/2:], 3, 2, 1)              (H/2) x (W/2), input of the 1x1 conv (-inf padding)
+// HBM-bound and small: one thread per (output pixel, 8-channel group); the averages are taken in fp32 as
+// ((p00 + p01) + (p10 + p11)) * 0.25 and rounded to fp16 once (max commutes with that monotone rounding).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ void avg4(const half_t* p, int ldx, int W, float (&o)[8]) {
+  const half8 a = *(const half8*)p, b = *(const half8*)(p + ldx), c = *(const half8*)(p + (long)W * ldx),
+              d = *(const half8*)(p + (long)W * ldx + ldx);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (((float)a[j] + (float)b[j]) + ((float)c[j] + (float)d[j])) * 0.25f;
+}
+
+__global__ __launch_bounds__(256) void adown_pool_kernel(const half_t* x, long x_bstride, int ldx, half_t* a, long a_bstride, int lda,
+                                                         half_t* m, long m_bstride, int ldm, int B, int H, int W, int C) {
+  const int cg = C / 16;                                   // 8-channel groups per half
+  const long na = (long)B * (H - 1) * (W - 1) * cg, nm = (long)B * (H / 2) * (W / 2) * cg;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na + nm; i += (long)gridDim.x * 256) {
+    if (i < na) {
+      const int g = (int)(i % cg);
+      long r = i / cg;
+      const int xx = (int)(r % (W - 1));
+      r /= (W - 1);
+      const int yy = (int)(r % (H - 1)), b = (int)(r / (H - 1));
+      float v[8];
+      avg4(x + b * x_bstride + ((long)yy * W + xx) * ldx + g * 8, ldx, W, v);
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)v[j];
+      *(half8*)(a + b * a_bstride + ((long)yy * (W - 1) + xx) * lda + g * 8) = o;
+    } else {
+      const long k = i - na;
+      const int g = (int)(k % cg);
+      long r = k / cg;
+      const int Wm = W / 2, Hm = H / 2;
+      const int xx = (int)(r % Wm);
+      r /= Wm;
+      const int yy = (int)(r % Hm), b = (int)(r / Hm);
+      float best[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) best[j] = -INFINITY;
+      for (int dy = -1; dy <= 1; ++dy) {
+        const int ay = 2 * yy + dy;
+        if (ay < 0 || ay > H - 2) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+          const int ax = 2 * xx + dx;
+          if (ax < 0 || ax > W - 2) continue;
+          float v[8];
+          avg4(x + b * x_bstride + ((long)ay * W + ax) * ldx + C / 2 + g * 8, ldx, W, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) best[j] = fmaxf(best[j], (float)(half_t)v[j]);
+        }
+      }
+      half8 o;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (half_t)best[j];
+      *(half8*)(m + b * m_bstride + ((long)yy * Wm + xx) * ldm + g * 8) = o;
+    }
+  }
+}
+}  // namespace
+
+int launch_adown_pool(const half_t* x, long x_bstride, int ldx, half_t* a, long a_bstride, int lda, half_t* m, long m_bstride,
+                      int ldm, int B, int H, int W, int C, hipStream_t s) {
+  if (C % 16 || ldx % 8 || lda % 8 || ldm % 8 || H < 2 || W < 2 || (H & 1) || (W & 1)) return -1;
+  const long n = (long)B * ((long)(H - 1) * (W - 1) + (long)(H / 2) * (W / 2)) * (C / 16);
+  long blocks = (n + 255) / 256;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(adown_pool_kernel, dim3((int)blocks), dim3(256), 0, s, x, x_bstride, ldx, a, a_bstride, lda, m, m_bstride, ldm,
+                     B, H, W, C);
+  return (int)hipGetLastError();
+}
+
 }  // namespace m355

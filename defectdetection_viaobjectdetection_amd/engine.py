@@ -13,7 +13,7 @@ import torch
 
 from . import _capi
 from ._capi import ConvInfo, ModelDesc, OpInfo, check, lib
-from .spec import ConvSpec, conv_specs, fold_bn
+from .spec import V9C, ConvSpec, conv_specs, fold_bn
 
 
 def _ptr(t: Optional[torch.Tensor]) -> C.c_void_p:
@@ -38,7 +38,7 @@ class SegEngine:
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             torch.cuda.init()
-            desc = ModelDesc(ord(scale), nc, imgsz[0], imgsz[1], max_batch)
+            desc = ModelDesc(ord("c" if scale == V9C else scale), nc, imgsz[0], imgsz[1], max_batch)   # 'c': yolov9c-seg
             check(lib.m355_create(C.byref(desc), C.byref(self._h)))
             check(lib.m355_set_keep_raw(self._h, int(keep_raw)), self._h)
         self.num_anchors = lib.m355_num_anchors(self._h)
@@ -59,6 +59,8 @@ class SegEngine:
         import math
         import os
         from .spec import SCALES
+        if scale == V9C:
+            return "M355_NO_PROTOFUSE" not in os.environ      # 256 prototype channels
         _, width, maxc = SCALES[scale]
         npr = int(math.ceil(min(256, maxc) * width / 8) * 8)
         return npr % 64 == 0 and "M355_NO_PROTOFUSE" not in os.environ

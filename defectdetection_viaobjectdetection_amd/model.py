@@ -22,9 +22,10 @@ import torch
 
 from .preprocess import expand_sources, letterbox, letterbox_shape, scale_boxes_to_original
 from .results import Results
-from .spec import SCALES, conv_specs, count_parameters, init_state_dict, state_dict_keys
+from .spec import SCALES, V9C, conv_specs, count_parameters, init_state_dict, state_dict_keys
 
 _YAML_RE = re.compile(r"^yolov8([nsmlx])?-seg\.ya?ml$")
+_V9C_RE = re.compile(r"^yolov9c-seg\.ya?ml$")
 CKPT_FORMAT = "mi355yolo-seg-v1"
 
 
@@ -57,10 +58,18 @@ class YOLO:
             if os.path.isfile(model):
                 self._read_yaml_overrides(model)
             self.state_dict = init_state_dict(self.scale, self.nc, seed=0)
+        elif _V9C_RE.match(name):
+            # the architecture the reference scripts literally name (/root/reference/BscanBased/yolo_seg_train.py:7)
+            self.scale = V9C
+            self.nc = 80
+            self.names = {i: f"class{i}" for i in range(self.nc)}
+            if os.path.isfile(model):
+                self._read_yaml_overrides(model)
+            self.state_dict = init_state_dict(self.scale, self.nc, seed=0)
         elif name.endswith((".yaml", ".yml")):
             raise NotImplementedError(
-                f"architecture '{name}' is not built yet: this package implements the YOLOv8{{n,s,m,l,x}}-seg graph "
-                "(BASELINE.json); yolov9c-seg / yolov5u / yolo11 are listed as next rows in SURVEY.md 8(f) N4")
+                f"architecture '{name}' is not built: this package implements the YOLOv8{{n,s,m,l,x}}-seg and YOLOv9c-seg "
+                "graphs; the detect-task families (yolov5u / yolo11) are listed as next rows in SURVEY.md 8(f) N4")
         elif name.endswith(".pt"):
             if not os.path.isfile(model):
                 raise OfflineModelError(
@@ -91,6 +100,8 @@ class YOLO:
         if missing:
             raise KeyError(f"state dict misses {len(missing)} keys, e.g. {missing[:3]}")
         for s in conv_specs(self.scale, self.nc):
+            if s.rep:
+                continue
             k = f"{s.name}.conv.weight" if s.has_bn else f"{s.name}.weight"
             if tuple(sd[k].shape) != s.weight_shape:
                 raise ValueError(f"{k}: shape {tuple(sd[k].shape)} != {s.weight_shape}")
@@ -217,6 +228,9 @@ class YOLO:
     # ------------------------------------------------------------------ training
     def train(self, data: Optional[str] = None, epochs: int = 100, imgsz: int = 640, batch: int = 16,
               project: Optional[str] = None, name: Optional[str] = None, device=0, **kwargs):
+        if self.scale == V9C:
+            raise NotImplementedError("yolov9c-seg: the inference graph is built (predict / val); its training graph (RepConvN "
+                                      "branches, ADown backward) is not -- train a yolov8{n,s,m,l,x}-seg model (SURVEY.md 8(f) N4)")
         from .train import train as _train  # lazy: training pulls in the loss / dataset modules
         return _train(self, data=data, epochs=epochs, imgsz=imgsz, batch=batch, project=project, name=name,
                       device=device, **kwargs)

@@ -18,6 +18,7 @@ import torch
 
 SCALES = {"n": (0.33, 0.25, 1024), "s": (0.33, 0.50, 1024), "m": (0.67, 0.75, 768),
           "l": (1.00, 1.00, 512), "x": (1.00, 1.25, 512)}
+V9C = "9c"     # the `scale` tag of the yolov9c-seg graph (SURVEY next row N4); the C-ABI descriptor carries it as 'c'
 REG_MAX = 16
 NM = 32
 BN_EPS = 1e-3
@@ -32,6 +33,7 @@ class ConvSpec:
     stride: int
     has_bn: bool       # Conv2d(bias=False)+BN+SiLU  vs plain Conv2d/ConvTranspose2d with bias
     transposed: bool = False
+    rep: bool = False  # RepConvN: act(Conv3x3+BN [name.conv1] + Conv1x1+BN [name.conv2]); the engine runs the merged 3x3
 
     @property
     def weight_shape(self):
@@ -42,8 +44,85 @@ def _make_divisible(x: float, d: int) -> int:
     return int(math.ceil(x / d) * d)
 
 
+def conv_specs_v9c(nc: int = 1) -> List[ConvSpec]:
+    """Canonical list of every convolution of yolov9c-seg (row N4; /root/reference/BscanBased/yolo_seg_train.py:7), in the
+    order ``libmi355yolo`` reports them.  Block structure: oracle/yolov9c_seg_oracle.py (exact published parameter counts)."""
+    out: List[ConvSpec] = []
+
+    def conv(name, cin, cout, k, s):
+        out.append(ConvSpec(name, cin, cout, k, s, True))
+
+    def repcsp(name, c1, c2):
+        c_ = c2 // 2
+        conv(f"{name}.cv1", c1, c_, 1, 1)
+        out.append(ConvSpec(f"{name}.m.0.cv1", c_, c_, 3, 1, True, False, True))
+        conv(f"{name}.m.0.cv2", c_, c_, 3, 1)
+        conv(f"{name}.cv2", c1, c_, 1, 1)
+        conv(f"{name}.cv3", 2 * c_, c2, 1, 1)
+
+    def elan(name, c1, c2, c3, c4):
+        conv(f"{name}.cv1", c1, c3, 1, 1)
+        repcsp(f"{name}.cv2.0", c3 // 2, c4)
+        conv(f"{name}.cv2.1", c4, c4, 3, 1)
+        repcsp(f"{name}.cv3.0", c4, c4)
+        conv(f"{name}.cv3.1", c4, c4, 3, 1)
+        conv(f"{name}.cv4", c3 + 2 * c4, c2, 1, 1)
+
+    def adown(name, c1, c2):
+        conv(f"{name}.cv1", c1 // 2, c2 // 2, 3, 2)
+        conv(f"{name}.cv2", c1 // 2, c2 // 2, 1, 1)
+
+    conv("model.0", 3, 64, 3, 2)
+    conv("model.1", 64, 128, 3, 2)
+    elan("model.2", 128, 256, 128, 64)
+    adown("model.3", 256, 256)
+    elan("model.4", 256, 512, 256, 128)
+    adown("model.5", 512, 512)
+    elan("model.6", 512, 512, 512, 256)
+    adown("model.7", 512, 512)
+    elan("model.8", 512, 512, 512, 256)
+    conv("model.9.cv1", 512, 256, 1, 1)
+    conv("model.9.cv5", 1024, 512, 1, 1)
+    elan("model.12", 1024, 512, 512, 256)
+    elan("model.15", 1024, 256, 256, 128)
+    adown("model.16", 256, 256)
+    elan("model.18", 768, 512, 512, 256)
+    adown("model.19", 512, 512)
+    elan("model.21", 1024, 512, 512, 256)
+    _segment_specs(out, nc, (256, 512, 512), 256)
+    return out
+
+
+def _segment_specs(out: List[ConvSpec], nc: int, fch, npr: int) -> None:
+    """model.22 = Segment: the box / class / coefficient branches per level and Proto (A9/A10), upstream state-dict order."""
+    hc2 = max(16, fch[0] // 4, REG_MAX * 4)
+    hc3 = max(fch[0], min(nc, 100))
+    hc4 = max(fch[0] // 4, NM)
+
+    def conv(name, cin, cout, k, s):
+        out.append(ConvSpec(name, cin, cout, k, s, True))
+    for l in range(3):
+        conv(f"model.22.cv2.{l}.0", fch[l], hc2, 3, 1)
+        conv(f"model.22.cv2.{l}.1", hc2, hc2, 3, 1)
+        out.append(ConvSpec(f"model.22.cv2.{l}.2", hc2, 4 * REG_MAX, 1, 1, False))
+    for l in range(3):
+        conv(f"model.22.cv3.{l}.0", fch[l], hc3, 3, 1)
+        conv(f"model.22.cv3.{l}.1", hc3, hc3, 3, 1)
+        out.append(ConvSpec(f"model.22.cv3.{l}.2", hc3, nc, 1, 1, False))
+    conv("model.22.proto.cv1", fch[0], npr, 3, 1)
+    out.append(ConvSpec("model.22.proto.upsample", npr, npr, 2, 2, False, True))
+    conv("model.22.proto.cv2", npr, npr, 3, 1)
+    conv("model.22.proto.cv3", npr, NM, 1, 1)
+    for l in range(3):
+        conv(f"model.22.cv4.{l}.0", fch[l], hc4, 3, 1)
+        conv(f"model.22.cv4.{l}.1", hc4, hc4, 3, 1)
+        out.append(ConvSpec(f"model.22.cv4.{l}.2", hc4, NM, 1, 1, False))
+
+
 def conv_specs(scale: str = "s", nc: int = 1) -> List[ConvSpec]:
-    """Canonical list of every convolution of yolov8{scale}-seg (A5/A9/A10)."""
+    """Canonical list of every convolution of yolov8{scale}-seg (A5/A9/A10); scale "9c": yolov9c-seg."""
+    if scale == V9C:
+        return conv_specs_v9c(nc)
     depth, width, maxc = SCALES[scale]
     ch = lambda c: _make_divisible(min(c, maxc) * width, 8)  # noqa: E731
     rep = lambda n: max(round(n * depth), 1) if n > 1 else n  # noqa: E731
@@ -102,13 +181,18 @@ def conv_specs(scale: str = "s", nc: int = 1) -> List[ConvSpec]:
     return out
 
 
+def conv_branches(s: ConvSpec):
+    """(state-dict prefix, kernel size) of the Conv2d+BN pairs behind one engine conv: itself, or RepConvN's two branches."""
+    return [(f"{s.name}.conv1", 3), (f"{s.name}.conv2", 1)] if s.rep else [(s.name, s.k)]
+
+
 def state_dict_keys(scale: str, nc: int) -> List[str]:
     keys = []
     for s in conv_specs(scale, nc):
         if s.has_bn:
-            keys += [f"{s.name}.conv.weight"] + [f"{s.name}.bn.{p}" for p in
-                                                 ("weight", "bias", "running_mean", "running_var",
-                                                  "num_batches_tracked")]
+            for pre, _ in conv_branches(s):
+                keys += [f"{pre}.conv.weight"] + [f"{pre}.bn.{p}" for p in
+                                                  ("weight", "bias", "running_mean", "running_var", "num_batches_tracked")]
         else:
             keys += [f"{s.name}.weight", f"{s.name}.bias"]
     keys.append("model.22.dfl.conv.weight")
@@ -139,12 +223,16 @@ def init_state_dict(scale: str = "s", nc: int = 1, seed: int = 0) -> Dict[str, t
         bound = 1.0 / math.sqrt(fan_in)
         w = (torch.rand(shape, generator=g) * 2 - 1) * bound
         if s.has_bn:
-            sd[f"{s.name}.conv.weight"] = w
-            sd[f"{s.name}.bn.weight"] = torch.ones(s.cout)
-            sd[f"{s.name}.bn.bias"] = torch.zeros(s.cout)
-            sd[f"{s.name}.bn.running_mean"] = torch.zeros(s.cout)
-            sd[f"{s.name}.bn.running_var"] = torch.ones(s.cout)
-            sd[f"{s.name}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+            for pre, k in conv_branches(s):
+                if s.rep:
+                    fi = s.cin * k * k
+                    w = (torch.rand((s.cout, s.cin, k, k), generator=g) * 2 - 1) / math.sqrt(fi)
+                sd[f"{pre}.conv.weight"] = w
+                sd[f"{pre}.bn.weight"] = torch.ones(s.cout)
+                sd[f"{pre}.bn.bias"] = torch.zeros(s.cout)
+                sd[f"{pre}.bn.running_mean"] = torch.zeros(s.cout)
+                sd[f"{pre}.bn.running_var"] = torch.ones(s.cout)
+                sd[f"{pre}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
         else:
             sd[f"{s.name}.weight"] = w
             sd[f"{s.name}.bias"] = (torch.rand(s.cout, generator=g) * 2 - 1) * bound
@@ -184,12 +272,15 @@ def synthetic_state_dict(scale: str = "s", nc: int = 1, seed: int = 0, cls_bias:
         bound = gain * math.sqrt(3.0 / fan_in)
         w = (torch.rand(shape, generator=g) * 2 - 1) * bound
         if s.has_bn:
-            sd[f"{s.name}.conv.weight"] = w
-            sd[f"{s.name}.bn.weight"] = 0.8 + 0.4 * torch.rand(s.cout, generator=g)
-            sd[f"{s.name}.bn.bias"] = 0.2 * torch.rand(s.cout, generator=g) - 0.1
-            sd[f"{s.name}.bn.running_mean"] = 0.2 * torch.rand(s.cout, generator=g) - 0.1
-            sd[f"{s.name}.bn.running_var"] = 0.8 + 0.4 * torch.rand(s.cout, generator=g)
-            sd[f"{s.name}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
+            for pre, k in conv_branches(s):
+                if s.rep:     # the two branches add up: each gets 1/sqrt(2) of the calibrated gain (one gain per RepConvN)
+                    w = (torch.rand((s.cout, s.cin, k, k), generator=g) * 2 - 1) * gain * math.sqrt(1.5 / (s.cin * k * k))
+                sd[f"{pre}.conv.weight"] = w
+                sd[f"{pre}.bn.weight"] = 0.8 + 0.4 * torch.rand(s.cout, generator=g)
+                sd[f"{pre}.bn.bias"] = 0.2 * torch.rand(s.cout, generator=g) - 0.1
+                sd[f"{pre}.bn.running_mean"] = 0.2 * torch.rand(s.cout, generator=g) - 0.1
+                sd[f"{pre}.bn.running_var"] = 0.8 + 0.4 * torch.rand(s.cout, generator=g)
+                sd[f"{pre}.bn.num_batches_tracked"] = torch.zeros((), dtype=torch.long)
         else:
             sd[f"{s.name}.weight"] = w
             sd[f"{s.name}.bias"] = 0.2 * torch.rand(s.cout, generator=g) - 0.1
@@ -203,6 +294,18 @@ def synthetic_state_dict(scale: str = "s", nc: int = 1, seed: int = 0, cls_bias:
 def fold_bn(sd: Dict[str, torch.Tensor], spec: ConvSpec):
     """A4: W' = W * gamma / sqrt(var + eps), b' = beta - mean * gamma / sqrt(var + eps).
     Returns (weight fp32 contiguous, bias fp32 contiguous) ready for ``m355_set_conv_weights``."""
+    if spec.rep:   # RepConvN: both branches folded, the 1x1 kernel added at the centre tap of the 3x3 (exact: conv is linear)
+        wsum = torch.zeros((spec.cout, spec.cin, 3, 3), dtype=torch.float64)
+        bsum = torch.zeros(spec.cout, dtype=torch.float64)
+        for pre, k in conv_branches(spec):
+            scale = sd[f"{pre}.bn.weight"].double() / torch.sqrt(sd[f"{pre}.bn.running_var"].double() + BN_EPS)
+            wk = sd[f"{pre}.conv.weight"].double() * scale.view(-1, 1, 1, 1)
+            if k == 3:
+                wsum += wk
+            else:
+                wsum[:, :, 1:2, 1:2] += wk
+            bsum += sd[f"{pre}.bn.bias"].double() - sd[f"{pre}.bn.running_mean"].double() * scale
+        return wsum.float().contiguous(), bsum.float().contiguous()
     if spec.has_bn:
         w = sd[f"{spec.name}.conv.weight"].double()
         gamma = sd[f"{spec.name}.bn.weight"].double()

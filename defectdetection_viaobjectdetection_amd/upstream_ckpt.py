@@ -175,12 +175,16 @@ def load_upstream_checkpoint(path: str) -> Dict:
     sd = OrderedDict((k, v.float() if v.is_floating_point() else v) for k, v in sd.items())
     stem = sd.get("model.0.conv.weight")
     cls0 = sd.get("model.22.cv3.0.2.weight")
+    is_v9c = "model.2.cv2.0.m.0.cv1.conv1.conv.weight" in sd and "model.9.cv5.conv.weight" in sd    # GELAN blocks
     if stem is None or cls0 is None or "model.22.proto.cv1.conv.weight" not in sd:
         kind = getattr(type(model), "_upstream", type(model).__name__)
         raise ValueError(f"{path}: not a YOLOv8-seg graph ({kind}); only yolov8{{n,s,m,l,x}}-seg is implemented "
                          "(SURVEY.md next row N4 lists yolov9c-seg / yolov5u / yolo11)")
     width = {16: "n", 32: "s", 48: "m", 64: "l", 80: "x"}.get(int(stem.shape[0]))
-    if width is None or width not in SCALES:
+    if is_v9c:
+        from .spec import V9C
+        width = V9C
+    if width is None or (width not in SCALES and not is_v9c):
         raise ValueError(f"{path}: stem width {int(stem.shape[0])} does not belong to a YOLOv8 scale")
     nc = int(cls0.shape[0])
     keys = state_dict_keys(width, nc)
@@ -188,6 +192,8 @@ def load_upstream_checkpoint(path: str) -> Dict:
     if missing:
         raise ValueError(f"{path}: {len(missing)} tensors of yolov8{width}-seg are missing, e.g. {missing[:3]}")
     for s in conv_specs(width, nc):
+        if s.rep:
+            continue
         k = f"{s.name}.conv.weight" if s.has_bn else f"{s.name}.weight"
         if tuple(sd[k].shape) != s.weight_shape:
             raise ValueError(f"{path}: {k} has shape {tuple(sd[k].shape)}, yolov8{width}-seg expects {s.weight_shape}")

@@ -1,4 +1,4 @@
-"""Generates defectdetection_viaobjectdetection_amd/data/synth_gains_{n,s,m}.json.
+"""Generates defectdetection_viaobjectdetection_amd/data/synth_gains_{n,s,m,9c}.json.
 
 One forward pass of the CPU oracle over seeded synthetic B-scans; a hook on every convolution measures
 the standard deviation of its output, divides the weights by it (so downstream layers see the
@@ -23,13 +23,33 @@ def calibrate(scale: str, nc: int = 1, seed: int = 0):
     specs = conv_specs(scale, nc)
     unit = {s.name: 1.0 for s in specs}
     sd = synthetic_state_dict(scale, nc, seed, gains=unit)
-    model = orc.SegmentationModel(scale, nc)
+    if scale == "9c":
+        import yolov9c_seg_oracle as o9
+        model = o9.SegmentationModelV9c(nc)
+    else:
+        model = orc.SegmentationModel(scale, nc)
     model.load_state_dict(sd, strict=True)
     model.eval()
     gains = {}
     by_mod = {}
     for s in specs:
-        by_mod[s.name + (".conv" if s.has_bn else "")] = s.name
+        if s.rep:      # RepConvN: ONE gain for the sum of its two branches, measured on the 3x3 branch's module output + the 1x1's
+            by_mod[s.name] = s.name
+        else:
+            by_mod[s.name + (".conv" if s.has_bn else "")] = s.name
+
+    def make_rep_hook(name):
+        # RepConvN.forward = silu(conv1(x) + conv2(x)): normalise the pre-activation sum by rescaling both branches
+        def pre(mod, inp):
+            x = inp[0]
+            z = mod.conv1(x) + mod.conv2(x)
+            std = float(z.std())
+            gains[name] = 1.0 / std
+            for br in (mod.conv1, mod.conv2):
+                br.conv.weight.data /= std
+                br.bn.bias.data /= std
+                br.bn.running_mean.data /= std
+        return pre
 
     def make_hook(name):
         def hook(mod, inp, out):
@@ -39,8 +59,11 @@ def calibrate(scale: str, nc: int = 1, seed: int = 0):
             return centred / std + (mod.bias.view(1, -1, 1, 1) if mod.bias is not None else 0.0)
         return hook
 
+    rep_names = {s.name for s in specs if s.rep}
     for n, mod in model.named_modules():
-        if n in by_mod:
+        if n in rep_names:
+            mod.register_forward_pre_hook(make_rep_hook(n))
+        elif n in by_mod:
             mod.register_forward_hook(make_hook(by_mod[n]))
     imgs = synthetic_bscans(2, seed=123)
     x = torch.from_numpy(imgs.transpose(0, 3, 1, 2).copy()).float() / 255.0
@@ -52,7 +75,7 @@ def calibrate(scale: str, nc: int = 1, seed: int = 0):
 if __name__ == "__main__":
     out_dir = os.path.join(ROOT, "defectdetection_viaobjectdetection_amd", "data")
     os.makedirs(out_dir, exist_ok=True)
-    for scale in ("n", "s", "m"):
+    for scale in (sys.argv[1:] or ("n", "s", "m", "9c")):
         g = calibrate(scale)
         with open(os.path.join(out_dir, f"synth_gains_{scale}.json"), "w") as f:
             json.dump({"scale": scale, "nc": 1, "seed": 0, "note": "see tests/golden/make_synth_gains.py",

@@ -121,8 +121,12 @@ def test_yolo_facade_offline_behaviour(tmp_path):
     from defectdetection_viaobjectdetection_amd.model import OfflineModelError, YOLO
     with pytest.raises(OfflineModelError):
         YOLO("yolov9c-seg.pt")                                  # yolo_seg_train.py:8 -- would download upstream
+    v9 = YOLO("yolov9c-seg.yaml")                               # yolo_seg_train.py:7 -- row N4: the graph exists now
+    assert v9.scale == "9c" and v9.nc == 80 and v9.info()[1] == 27897120    # the published yolov9c-seg parameter count
+    with pytest.raises(NotImplementedError, match="training graph"):
+        v9.train(data="data-seg.yaml", epochs=1)
     with pytest.raises(NotImplementedError):
-        YOLO("yolov9c-seg.yaml")                                # yolo_seg_train.py:7 -- next row N4
+        YOLO("yolo11n-seg.yaml")                                # detect / other families: still next rows
     m = YOLO("yolov8n-seg.yaml")
     assert m.scale == "n" and m.nc == 80 and m.info()[1] == 3409968
     m.set_classes(1, {0: "defect"})
