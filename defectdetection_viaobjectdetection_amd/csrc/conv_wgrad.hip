@@ -18,6 +18,8 @@
 // adds the slabs in split order -- bitwise reproducible gradients (float atomics made two runs of one batch differ, and
 // a 60-layer fp16-storage backward amplifies such last-bit differences to 1e-2 in the early layers: DESIGN.md section 8).
 // One split (small layers): the tile goes straight to dW.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace m355 {
@@ -206,7 +208,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
 void wgrad_plan(int M, int Cout, int N, int* splitk, int* steps_per_split) {
   const int tiles = ((Cout + 127) / 128) * ((N + 127) / 128);
   const int steps_total = (M + KST - 1) / KST;
-  int sk = (1024 + tiles - 1) / tiles;   // ~2 waves of blocks over 256 CUs x 2 resident blocks
+  // every block writes one 64 KB partial tile: the slab traffic of a layer is (blocks x 64 KB), so no more blocks than
+  // fill three quarters of the chip once (256 CUs x 2 resident blocks); M355_WGRAD_BLOCKS overrides for tuning
+  static const int target = getenv("M355_WGRAD_BLOCKS") ? atoi(getenv("M355_WGRAD_BLOCKS")) : 384;   // measured (s-seg b64 @640 step): 256 -> 49.0 ms, 384 -> 46.1, 512 -> 47.7, 1024 -> 49.3
+  int sk = (target + tiles - 1) / tiles;
   if (sk > steps_total) sk = steps_total;
   if (sk < 1) sk = 1;
   *steps_per_split = (steps_total + sk - 1) / sk;

@@ -3,9 +3,10 @@
 // from SegmentationModel.forward in training mode (call site BscanBased/yolo_seg_train.py:12).
 // All HBM-bound: one 16-byte chunk (8 channels) per lane, per-channel fp32 partial sums in registers,
 // block reduction through LDS, then a DETERMINISTIC cross-block reduction: every block stores its 2C partial sums
-// to a workspace row, takes a ticket (agent-scope release + relaxed atomic), and the block that draws the last
-// ticket adds the rows in block order after an agent-scope acquire (cdna_hip_programming.md Guideline 16, counter
-// form).  No float atomics: two runs of one batch give the same bits.
+// to a workspace row and a small second kernel (one block per 64 columns) adds the rows in a fixed order.  No float
+// atomics: two runs of one batch give the same bits.  (An in-kernel "last ticket adds the rows" form was measured at
+// ~100 us per launch: one block reading 256 rows is a serial tail; the separate kernel costs what the memset of the
+// atomic version did -- one more stream operation.)
 #include "common.h"
 
 namespace m355 {
@@ -15,12 +16,11 @@ constexpr int BN_THREADS = 256;
 
 __device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
-constexpr int WS_HEAD = 4;   // floats in front of the partial rows: [0] = ticket (as unsigned), rest padding to 16 bytes
+constexpr int WS_HEAD = 4;   // floats in front of the partial rows (kept 16-byte aligned)
 
-// Tail of the two reduction kernels.  red[] holds every thread's 16 partial sums (8 channels x 2 kinds); on return
-// out[0:2C] holds the sums over ALL blocks (written by the last-arriving block; the ticket is back to zero).
-__device__ __forceinline__ void ordered_block_reduce(float* red, int C, int cg, int lanes_px, float* ws, float* out) {
-  unsigned* const ticket = (unsigned*)ws;
+// Tail of the two reduction kernels: this block's 2C partial sums (red[] holds every thread's 16) go to row blockIdx.x
+// of the workspace with plain stores; bn_finalize_kernel adds the rows in block order.
+__device__ __forceinline__ void store_block_partials(const float* red, int C, int cg, int lanes_px, float* ws) {
   float* const part = ws + WS_HEAD;
   const int n2 = 2 * C;
   for (int t = threadIdx.x; t < n2; t += BN_THREADS) {
@@ -30,32 +30,35 @@ __device__ __forceinline__ void ordered_block_reduce(float* red, int C, int cg, 
     for (int l = 0; l < lanes_px; ++l) acc += red[(l * cg + g) * 16 + kind * 8 + j];
     part[(long)blockIdx.x * n2 + t] = acc;
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // every storing wave drains its stores
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the fence's write-back before the ticket (ROCm 7.2 may drop the fence's own wait)
-    const unsigned tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const bool last = tk == gridDim.x - 1;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    red[BN_THREADS * 16] = last ? 1.f : 0.f;
-  }
-  __syncthreads();
-  if (red[BN_THREADS * 16] == 0.f) return;
-  for (int t = threadIdx.x; t < n2; t += BN_THREADS) {
-    float acc = 0.f;
-    for (int b = 0; b < (int)gridDim.x; ++b) acc += part[(long)b * n2 + t];   // block order: fixed association
-    out[t] = acc;
-  }
-  if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
 }
 
-// sums[0:C] = sum_px z, sums[C:2C] = sum_px z^2   (ws: WS_HEAD + gridDim.x * 2C floats, ticket zero on entry)
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const half_t* z, long npix, int ld, int C, float* sums, float* ws) {
-  extern __shared__ float red[];  // [BN_THREADS][16] + 1 flag
+// out[t] = sum over rows b = 0 .. rows-1 of part[b][t], FIXED association: wave w adds rows w, w+4, ... in order into one
+// accumulator (loads issued eight ahead), then the four wave sums are added in wave order.  One block per 64 columns.
+__global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const float* ws, int n2, int rows, float* out) {
+  __shared__ float wsum[4][64];
+  const float* const part = ws + WS_HEAD;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (col < n2) {
+    int b = w;
+    for (; b + 28 < rows; b += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(b + 4 * u) * n2 + col];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; b < rows; b += 4) acc += part[(long)b * n2 + col];
+  }
+  wsum[w][lane] = acc;
+  __syncthreads();
+  if (w == 0 && col < n2) out[col] = ((wsum[0][lane] + wsum[1][lane]) + wsum[2][lane]) + wsum[3][lane];
+}
+
+// partial rows of sum_px z (columns 0:C) and sum_px z^2 (C:2C)   (ws: WS_HEAD + gridDim.x * 2C floats)
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const half_t* z, long npix, int ld, int C, float* ws) {
+  extern __shared__ float red[];  // [BN_THREADS][16]
   const int cg = C / 8;                       // channel groups
   const int lanes_px = BN_THREADS / cg;       // pixel lanes per block (threads beyond lanes_px * cg idle)
   const int cgi = threadIdx.x % cg, pl = threadIdx.x / cg;
@@ -96,7 +99,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_kernel(const half_t* z, l
     red[threadIdx.x * 16 + 8 + j] = q[j];
   }
   __syncthreads();
-  ordered_block_reduce(red, C, cg, lanes_px, ws, sums);
+  store_block_partials(red, C, cg, lanes_px, ws);
 }
 
 // mean / invstd from the sums (biased variance, like torch batch_norm in training mode), optional
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_apply_kernel(const half_t*
 __global__ __launch_bounds__(BN_THREADS) void bn_silu_bwd_reduce_kernel(const half_t* z, const half_t* dy, long npix,
                                                                         int ldz, int lddy, int C, const float* mean,
                                                                         const float* invstd, const float* gamma,
-                                                                        const float* beta, float* rsum, int act, float* ws) {
+                                                                        const float* beta, int act, float* ws) {
   extern __shared__ float red[];
   const int cg = C / 8;
   const int lanes_px = BN_THREADS / cg;
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_silu_bwd_reduce_kernel(const ha
     red[threadIdx.x * 16 + 8 + j] = q[j];
   }
   __syncthreads();
-  ordered_block_reduce(red, C, cg, lanes_px, ws, rsum);
+  store_block_partials(red, C, cg, lanes_px, ws);
 }
 
 // dz = gamma * invstd * (du - dbeta / N - xhat * dgamma / N); same thread-owns-a-channel-group walk as the forward
@@ -317,12 +320,11 @@ __global__ __launch_bounds__(256) void sgd_step_kernel(float* p, const float* g,
 }
 
 // out[0] = sum g^2 over the finite entries, out[1] = number of non-finite entries.  Deterministic: wave shuffle reduction,
-// the four wave sums of a block added in wave order, one partial pair per block in out[8 + 2 b], last ticket adds them
-// in block order (same protocol as ordered_block_reduce).  out: SUMSQ_WS floats, out[4] = ticket (zero on entry).
+// the four wave sums of a block added in wave order, one partial pair per block in out[8 + 2 b]; grad_sumsq_final_kernel
+// (one block) adds them in block order.  out: SUMSQ_WS floats.
 constexpr int SUMSQ_BLOCKS = 1024, SUMSQ_WS = 8 + 2 * SUMSQ_BLOCKS;
 __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long n, float* out) {
   __shared__ float wsum[8];
-  __shared__ int is_last;
   float s = 0.f, bad = 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     const float x = g[i];
@@ -341,22 +343,12 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long n,
   if (threadIdx.x == 0) {
     out[8 + 2 * blockIdx.x] = ((wsum[0] + wsum[2]) + wsum[4]) + wsum[6];
     out[9 + 2 * blockIdx.x] = ((wsum[1] + wsum[3]) + wsum[5]) + wsum[7];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned tk = __hip_atomic_fetch_add((unsigned*)(out + 4), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    is_last = tk == gridDim.x - 1;
-    if (is_last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
   }
-  __syncthreads();
-  if (!is_last) return;
-  // the last block: 256 threads x 4 blocks each in block order, then the thread partials in thread order
+}
+__global__ __launch_bounds__(256) void grad_sumsq_final_kernel(float* out, int nblocks) {
   __shared__ float ts[256], tb[256];
   float a0 = 0.f, a1 = 0.f;
-  for (int b = threadIdx.x * 4; b < threadIdx.x * 4 + 4 && b < (int)gridDim.x; ++b) {
+  for (int b = threadIdx.x * 4; b < threadIdx.x * 4 + 4 && b < nblocks; ++b) {   // 4 consecutive blocks per thread, in order
     a0 += out[8 + 2 * b];
     a1 += out[9 + 2 * b];
   }
@@ -365,10 +357,9 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const float* g, long n,
   __syncthreads();
   if (threadIdx.x == 0) {
     float t0 = 0.f, t1 = 0.f;
-    for (int i = 0; i < 256; ++i) { t0 += ts[i]; t1 += tb[i]; }
+    for (int i = 0; i < 256; ++i) { t0 += ts[i]; t1 += tb[i]; }               // thread partials in thread order
     out[0] = t0;
     out[1] = t1;
-    __hip_atomic_store((unsigned*)(out + 4), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -397,8 +388,7 @@ int grid_px(long npix, int lanes_px) {
 
 size_t bn_workspace_floats(int C) { return (size_t)WS_HEAD + (size_t)256 * 2 * C + 2 * C; }
 
-// ws: bn_workspace_floats(C) floats, zero-initialised ONCE by the caller (the ticket returns to zero after every launch);
-// the batch sums land in ws[WS_HEAD + 256 * 2C ...]
+// ws: bn_workspace_floats(C) floats (per-block partial rows, then the 2C batch sums at ws[WS_HEAD + 256 * 2C ...])
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
                              float eps, half_t* y, int ldy, const half_t* res, int ldr, float* sums, float* mean_out,
                              float* invstd_out, int act, float* run_mean, float* run_var, float momentum, hipStream_t s) {
@@ -406,8 +396,9 @@ int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const f
   const int lanes_px = BN_THREADS / (C / 8);
   float* const ws = sums;
   float* const tot = ws + WS_HEAD + (size_t)256 * 2 * C;
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(grid_red(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
-                     (BN_THREADS * 16 + 4) * sizeof(float), s, z, npix, ldz, C, tot, ws);
+  const int gr = grid_red(npix * BN_THREADS / lanes_px / 4);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(gr), dim3(BN_THREADS), BN_THREADS * 16 * sizeof(float), s, z, npix, ldz, C, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((2 * C + 63) / 64), dim3(BN_THREADS), 0, s, ws, 2 * C, gr, tot);
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, npix, ldz, C, tot,
                      gamma, beta, eps, y, ldy, res, ldr, mean_out, invstd_out, act, run_mean, run_var, momentum);
   return (int)hipGetLastError();
@@ -419,8 +410,10 @@ int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int l
                              int lddz, int act, float* ws, hipStream_t s) {
   if (C % 8 || ldz % 8 || lddy % 8 || lddz % 8 || C / 8 > BN_THREADS || !ws) return -1;
   const int lanes_px = BN_THREADS / (C / 8);
-  hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(grid_red(npix * BN_THREADS / lanes_px / 4)), dim3(BN_THREADS),
-                     (BN_THREADS * 16 + 4) * sizeof(float), s, z, dy, npix, ldz, lddy, C, mean, invstd, gamma, beta, rsum, act, ws);
+  const int gr = grid_red(npix * BN_THREADS / lanes_px / 4);
+  hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(gr), dim3(BN_THREADS), BN_THREADS * 16 * sizeof(float), s, z, dy, npix, ldz,
+                     lddy, C, mean, invstd, gamma, beta, act, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((2 * C + 63) / 64), dim3(BN_THREADS), 0, s, ws, 2 * C, gr, rsum);
   hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
                      lddy, C, mean, invstd, gamma, beta, rsum, dz, lddz, act);
   return (int)hipGetLastError();
@@ -452,6 +445,7 @@ int launch_grad_sumsq(const float* g, long n, float* out, hipStream_t s) {
   int blocks = grid_for(n);
   if (blocks > SUMSQ_BLOCKS) blocks = SUMSQ_BLOCKS;
   hipLaunchKernelGGL(grad_sumsq_kernel, dim3(blocks), dim3(256), 0, s, g, n, out);
+  hipLaunchKernelGGL(grad_sumsq_final_kernel, dim3(1), dim3(256), 0, s, out, blocks);
   return (int)hipGetLastError();
 }
 

@@ -144,9 +144,8 @@ int m355_conv2d_wgrad(const void* d_x_f16_nhwc, const void* d_dy_f16_nhwc, int B
                       int k, int stride, float* d_dw_krsc, void* stream);
 /* Train-mode BatchNorm2d (batch statistics, biased variance, eps) + optional SiLU on fp16 NHWC (B,H,W,C)
  * (SURVEY A13): y = act(gamma * (z - mean) * invstd + beta).  gamma/beta/mean/invstd/ws are DEVICE fp32 arrays;
- * d_ws is a workspace of m355_bn_workspace_floats(C) floats that the caller zero-initialises ONCE (per-block partial sums
- * + a ticket that returns to zero after every launch: the cross-block reduction runs in block order, no float atomics,
- * bitwise reproducible); d_mean/d_invstd receive the saved statistics. */
+ * d_ws is a workspace of m355_bn_workspace_floats(C) floats (per-block partial sums; a second small kernel adds them in
+ * block order: no float atomics, bitwise reproducible); d_mean/d_invstd receive the saved statistics. */
 size_t m355_bn_workspace_floats(int C);
 int m355_bn_silu_train_fwd(const void* d_z, int B, int H, int W, int C, const float* d_gamma, const float* d_beta,
                            float eps, int act, void* d_y, float* d_mean, float* d_invstd, float* d_ws, void* stream);
@@ -229,8 +228,8 @@ int m355_sgd_step(float* p, const float* g, float* momentum_buf, float* ema, con
                   float lr_bias, float momentum, int32_t nesterov, float weight_decay, float grad_mul, float ema_decay,
                   void* stream);
 /* out[0] = sum of squares of the finite entries of g, out[1] = number of non-finite entries.  `out` is a DEVICE buffer of
- * m355_grad_sumsq_workspace_floats() floats, zero-initialised once by the caller (block partials + ticket behind the two
- * results): fixed reduction order, bitwise reproducible. */
+ * m355_grad_sumsq_workspace_floats() floats (the block partials sit behind the two results; a one-block kernel adds them
+ * in block order): fixed reduction order, bitwise reproducible. */
 size_t m355_grad_sumsq_workspace_floats(void);
 int m355_grad_sumsq(const float* g, int64_t n, float* out, void* stream);
 
