@@ -66,6 +66,10 @@ struct ConvArgs {
   // engine's padding).  Every launcher refuses a channel tile whose ceil(Cout / tile) * tile rows exceed it: the
   // kernels fetch whole weight-row tiles by LDS-DMA with no per-row bound.
   int w_rows;
+  // Tile queue of the persistent kernels: two ints in device memory, zero before the first launch (the kernel re-arms
+  // them): [0] tiles claimed beyond each block's static first one, [1] blocks that have left.  nullptr: static walk.
+  // One queue per op -- never shared by launches that can run at the same time.
+  int* tileq;
 };
 
 // tile ids for launch_conv_igemm(force_tile)
@@ -73,7 +77,7 @@ enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {
-  bool no_fast_epi, no_wide, no_persist, stem_gather, lean, no_m32;
+  bool no_fast_epi, no_wide, no_persist, stem_gather, lean, no_m32, static_tiles;
   int persist, halo_variant, smallm;
 };
 const Knobs& knobs();
@@ -101,6 +105,9 @@ int launch_conv3x3_wide(const ConvArgs& a, hipStream_t s);
 // v_mfma_f32_32x32x16_f16 halo kernel (conv3x3_m32.hip); which: 0 = by shape, 1 = <128 ch, 8 rows>, 2 = <64, 16>, 3 = <64, 8>
 bool conv3x3_m32_ok(const ConvArgs& a);
 int launch_conv3x3_m32(const ConvArgs& a, int which, hipStream_t s);
+// Conv3x3 / s2 (32 -> 64) + Conv1x1 (64 -> 64) in one persistent patch kernel (conv3x3_s2c32.hip): a.w2 / a.bias2 / a.cout2 set
+bool conv_s2c32_cv1_ok(const ConvArgs& a);
+int launch_conv_s2c32_cv1(const ConvArgs& a, hipStream_t s);
 // narrow maps (W <= 26): slabs of full-width rows, linear pixel groups (conv3x3_small.hip)
 bool conv3x3_slab_ok(const ConvArgs& a);
 int launch_conv3x3_slab(const ConvArgs& a, hipStream_t s);

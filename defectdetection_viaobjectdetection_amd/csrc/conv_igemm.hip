@@ -773,6 +773,7 @@ const Knobs& knobs() {
     v.no_wide = getenv("M355_NO_WIDE") != nullptr;
     v.lean = getenv("M355_LEAN") != nullptr;
     v.no_m32 = getenv("M355_NO_M32") != nullptr;
+    v.static_tiles = getenv("M355_STATIC_TILES") != nullptr;   // persistent kernels: static tile walk instead of the queue
     v.no_persist = getenv("M355_NO_PERSIST") != nullptr;
     v.stem_gather = getenv("M355_STEM_GATHER") != nullptr;
     v.persist = getenv("M355_PERSIST") ? atoi(getenv("M355_PERSIST")) : 0;

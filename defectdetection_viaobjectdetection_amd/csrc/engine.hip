@@ -59,6 +59,7 @@ struct Op {
   double wbytes = 0;      // weight bytes (read once per launch)
   int tile = -1;
   int decode = 0;         // head output conv that also decodes its rows into the prediction tensor (no OP_DECODE launch)
+  int s2c32 = 0;          // conv 3x3/s2 (32 -> 64) + 1x1 (64 -> 64) on the dedicated patch kernel (conv3x3_s2c32.hip)
   // stream lanes (plan_lanes): lane 0 is the caller's stream, lanes >= 1 are engine-owned side streams
   int lane = 0;
   std::vector<int> wait_ops;   // ops on OTHER lanes whose completion event this op's stream waits for before the launch
@@ -101,6 +102,7 @@ struct m355_engine {
   int proto_h = 0, proto_w = 0;
   float* raw = nullptr;      // (max_batch, A, 64+nc+nm) fp32
   half_t* zero = nullptr;    // zero page
+  int* tileq = nullptr;      // tile queues of the persistent kernels, 4 ints per op (ConvArgs.tileq)
   void* nms_ws = nullptr;
   size_t nms_ws_bytes = 0;
   size_t ws_bytes = 0;
@@ -757,6 +759,8 @@ int alloc_all(m355_engine* e) {
   total += raw_bytes;
   HIP_TRY(e, hipMalloc((void**)&e->zero, 4096));
   HIP_TRY(e, hipMemset(e->zero, 0, 4096));
+  HIP_TRY(e, hipMalloc((void**)&e->tileq, (e->ops.size() + 1) * 16));   // one tile queue (ConvArgs.tileq) per op
+  HIP_TRY(e, hipMemset(e->tileq, 0, (e->ops.size() + 1) * 16));
   e->nms_ws_bytes = nms_workspace_bytes((int)B, e->A);
   HIP_TRY(e, hipMalloc(&e->nms_ws, e->nms_ws_bytes));
   total += e->nms_ws_bytes + 4096;
@@ -856,6 +860,11 @@ void annotate_ops(m355_engine* e) {
         }
         if (op.kind == OP_CONV && p.l3 >= 0) {   // + the 1x1 conv in the epilogue
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d+1x1>", tile_names[op.tile], k);
+          if (p.k == 3 && p.stride == 2 && p.cin == 32 && p.cout == 64 && p.cout2 == 64 && Ho % 8 == 0 && Wo % 16 == 0 &&
+              !getenv("M355_NO_S2C32")) {
+            op.s2c32 = 1;
+            snprintf(op.kernel, sizeof(op.kernel), "conv3x3_s2c32<8x16px>+1x1");
+          }
           snprintf(op.layer, sizeof(op.layer), "%s+%s", e->convs[p.logical[0]].name, e->convs[p.l3].name);
           op.flops += 2.0 * Ho * Wo * (double)p.cout * p.cout2;
         }
@@ -981,6 +990,7 @@ void m355_destroy(m355_engine* e) {
   }
   if (e->raw) (void)hipFree(e->raw);
   if (e->zero) (void)hipFree(e->zero);
+  if (e->tileq) (void)hipFree(e->tileq);
   if (e->nms_ws) (void)hipFree(e->nms_ws);
   for (hipEvent_t ev : e->ev_pool) (void)hipEventDestroy(ev);
   for (hipEvent_t ev : e->op_done)
@@ -1225,7 +1235,9 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           const PhysConv& pf = e->phys[op.conv];
           a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2;
         }
-        rc = (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
+        a.tileq = knobs().static_tiles ? nullptr : e->tileq + 4 * oi;
+        rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
+             : (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
              : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
                                     : (op.tile == TILE_SLAB ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, op.tile, s)));
         break;

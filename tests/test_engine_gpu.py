@@ -307,6 +307,7 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
     import os
     from defectdetection_viaobjectdetection_amd.engine import SegEngine
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    os.environ["M355_NO_S2C32"] = "1"       # the 32 -> 64 pair has its own patch kernel by default (next test); this one is about the epilogue fusion
     for scale, nfused in (("s", 2), ("n", 1)):
         sd = synthetic_state_dict(scale, 1, seed=0)
         # 7 images of 608 x 640: the 76 x 80 map of model.3 gives 332.5 pixel tiles (a partial one), enough for the 128-channel tile
@@ -330,6 +331,40 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
         if saved is not None:
             os.environ["M355_NO_CVFUSE"] = saved
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), scale
+    os.environ.pop("M355_NO_S2C32", None)
+
+
+def test_s2c32_patch_kernel_matches_the_im2col_form(cuda_device):
+    """model.1 + model.2.cv1 of the s scale on conv3x3_s2c32.hip (32x32x16 MFMA, staged patch, resident weights) against the
+    same pair on the im2col kernel with the epilogue fusion: same fp16 intermediate, different summation order.  Every later
+    layer is identical in the two engines, so the network outputs may differ by the ulp-level noise a deep fp16 network
+    amplifies (~1e-3) and no more; a wrong tap, channel or pixel mapping would be an O(1) difference
+    (and fails test_forward_parity against the oracle as well)."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(5, seed=33)).to(cuda_device)
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ["M355_NO_S2C32"] = "1"
+        try:
+            eng = SegEngine("s", 1, (640, 640), max_batch=5)
+        finally:
+            os.environ.pop("M355_NO_S2C32", None)
+        kinds = [o["kernel"] for o in eng.op_infos()]
+        assert any("s2c32" in k for k in kinds) == (not off), kinds
+        eng.load_state_dict(sd)
+        p, q = eng.forward(imgs)
+        raw = eng.raw_head(5)
+        torch.cuda.synchronize()
+        outs.append((p.clone(), q.clone(), raw.clone()))
+        eng.close()
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    e_raw, e_pr = rel(outs[0][2], outs[1][2]), rel(outs[0][1], outs[1][1])
+    print(f"s2c32 vs im2col form: raw head rel-L2 {e_raw:.2e}, prototypes rel-L2 {e_pr:.2e}")
+    assert e_raw <= 2e-3 and e_pr <= 2e-3
 
 
 def test_sub_batched_leading_ops_are_bit_identical(cuda_device):
