@@ -91,6 +91,7 @@ def main():
         os.environ["M355_NO_LANES"] = "1"
         os.environ["M355_NO_SUBBATCH"] = "1"
         args.engines = 1
+        args.no_overlap = True      # post-processing on the forward stream too: nothing runs beside any kernel
     n_eng = max(1, args.engines)
     if args.lanes == "off" or (args.lanes == "auto" and n_eng > 1):
         os.environ["M355_NO_LANES"] = "1"
@@ -125,9 +126,13 @@ def main():
     P = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
     step_no = [0]
     last_fwd = [None]     # event after the most recent forward (any engine)
+    last_post = [None] * n_eng   # event after the most recent post-processing of each engine
 
     def step(alone=False):
-        """alone: this forward does not overlap any other forward (event-sampled steps: per-kernel times are clean)."""
+        """alone: this forward overlaps nothing -- no other forward and no post-processing of an earlier batch (event-sampled
+        steps: per-kernel times are clean).  A persistent kernel that needs a whole CU's LDS is not even dispatched while
+        the mask kernel's small blocks keep refilling the CUs: measured on the model.1 patch kernel, 90 us from its first
+        wave's entry to its last wave's exit (s_memrealtime) but 180 us between its events."""
         i = step_no[0]
         step_no[0] += 1
         e, k = i % n_eng, (i // n_eng) % nbuf
@@ -136,6 +141,10 @@ def main():
             sf.wait_event(ev_post[e][k])          # the post-processing that last read this buffer set is done
         if (alone or step.prev_alone) and last_fwd[0] is not None:
             sf.wait_event(last_fwd[0])            # serialise against the previous forward (other engine's stream)
+        if alone:
+            for ev in last_post:
+                if ev is not None:
+                    sf.wait_event(ev)
         check(lib.m355_forward(engs[e]._h, P(imgs_all[i % n_in]), B, P(preds[e][k]), P(protos[e][k]), C.c_void_p(sf.cuda_stream)), engs[e]._h)
         ev_fwd[e][k].record(sf)
         last_fwd[0] = ev_fwd[e][k]
@@ -146,6 +155,7 @@ def main():
                                    P(counts_b[e][k]), P(masks[e][k]), C.c_void_p(sp.cuda_stream)), engs[e]._h)
         if nbuf == 2:
             ev_post[e][k].record(sp)
+            last_post[e] = ev_post[e][k]
     step.prev_alone = False
 
     def barrier():
@@ -207,7 +217,7 @@ def main():
                    "engines_in_flight": n_eng, "stream_lanes_per_engine": 1 if os.environ.get("M355_NO_LANES") else 3,
                    "pipelining": ("none" if args.no_overlap and n_eng == 1 else
                                   f"{n_eng} batch(es) in flight on {n_eng} engine instance(s); post-processing of a batch "
-                                  f"overlaps later forwards (own HIP stream); event-sampled steps run their forward alone")},
+                                  f"overlaps later forwards (own HIP stream); event-sampled steps run their forward alone (no other forward, no post-processing beside it)")},
     }
     if rank == 0:
         gflop_img = eng.flops_per_image / 1e9

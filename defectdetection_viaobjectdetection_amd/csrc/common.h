@@ -70,6 +70,7 @@ struct ConvArgs {
   // them): [0] tiles claimed beyond each block's static first one, [1] blocks that have left.  nullptr: static walk.
   // One queue per op -- never shared by launches that can run at the same time.
   int* tileq;
+  int bias_lds;        // set by the implicit-GEMM launcher: this many bias floats are staged in LDS behind the stages (0: none)
 };
 
 // tile ids for launch_conv_igemm(force_tile)
@@ -77,7 +78,7 @@ enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {
-  bool no_fast_epi, no_wide, no_persist, stem_gather, lean, no_m32, static_tiles;
+  bool no_fast_epi, no_wide, no_persist, stem_gather, lean, no_m32, static_tiles, no_bias_lds;
   int persist, halo_variant, smallm;
 };
 const Knobs& knobs();

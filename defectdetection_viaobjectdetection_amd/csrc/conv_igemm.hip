@@ -249,6 +249,11 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
   float4v acc[MT][NT];
   half8 af0[MT], bf0[NT], af1[MT], bf1[NT];
 
+  // Biases in LDS (a.bias_lds floats behind the two stages; launch_variant sized the allocation): a persistent block reads
+  // the bias of every tile it walks, and an ordinary VGPR load issued while LDS-DMA is in flight makes hipcc wait vmcnt(0)
+  // at its first use -- that drained the next tile's two prefetched stages at the top of every epilogue.
+  float* const bias_s = (float*)(smem + 2 * STAGE);
+  for (int i = tid; i < a.bias_lds; i += NW * 64) bias_s[i] = a.bias[i];
   // ---- pipeline prologue: two stages in flight, fragments ks=0 of stage 0 in registers
   loader_setup(ld_tile);
   stage_next();
@@ -269,8 +274,12 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
   //   mid : vmcnt(0)+lgkmcnt(0)+barrier => stage gs+1 has landed for every wave and every wave is
   //         done reading stage gs -> issue ds_reads ks=0(gs+1), LDS-DMA for stage gs+2 into buffer
   //         gs&1 -> 16 MFMA ks=1(gs)
+  // after_stores: this is the first K step of a tile that follows a fast epilogue in the same block (persistent walk).  That
+  // epilogue's NST stores per lane were issued AFTER the two stages this step needs (vmcnt retires in issue order), so the
+  // wait leaves them in flight instead of draining them: ~1-2 us per tile on the 1x1 layers.
+  constexpr int NST = (MT >= 2 ? MT / 2 : 1) * NT;
   int gs = 0;
-  auto kstep = [&]() __attribute__((always_inline)) {
+  auto kstep = [&](const bool after_stores) __attribute__((always_inline)) {
     const char* sb = smem + (gs & 1) * STAGE;
     const char* sn = smem + ((gs + 1) & 1) * STAGE;
 #pragma unroll
@@ -282,7 +291,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af0[mt], bf0[nt], acc[mt][nt], 0, 0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (after_stores) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(NST) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     if (!(a.dbg & 8)) __builtin_amdgcn_s_barrier();
     // ks=0 fragments of the next stage (after the very last stage this reads stale bytes, never used)
 #pragma unroll
@@ -301,6 +311,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
   constexpr int GROUPS = (MT >= 2) ? MT / 2 : 1;  // 8-channel (MT>=2) or 4-channel (MT==1) groups per lane
   constexpr int GW = (MT >= 2) ? 8 : 4;
 
+  bool stores_pending = false;
   for (int tile = lb; tile < total; tile += nwg) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -319,7 +330,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     const bool fast_t = MT >= 2 && !a.out_f32 && a.convt_co > 0 && a.convt_co % BCH == 0 && a.Wo % 16 == 0 && !a.res &&
                         px_base + BPX <= a.M && ch_base + BCH <= a.Cout && !(a.dbg & (32 | 256));
     float4v bv[MT >= 2 ? MT / 2 : 1][2];
-    if (fast || fast_t) {
+    if ((fast || fast_t) && !a.bias_lds) {
       const int cb0 = fast_t ? ch_base % a.convt_co : ch_base;   // the bias is indexed by the real output channel
       const float* bp = a.bias + cb0 + wch * MT * 16 + g * 8;
 #pragma unroll
@@ -329,7 +340,18 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       }
     }
     if (a.stamps && tile == lb) st1 = __builtin_amdgcn_s_memtime();
-    for (int t = 0; t < nk; ++t) kstep();
+    kstep(stores_pending);
+    for (int t = 1; t < nk; ++t) kstep(false);
+    stores_pending = false;
+    if ((fast || fast_t) && a.bias_lds) {   // (every wave passed the prologue barrier after the staging loop)
+      const int cb0 = fast_t ? ch_base % a.convt_co : ch_base;
+      const float* bp = bias_s + cb0 + wch * MT * 16 + g * 8;
+#pragma unroll
+      for (int sg = 0; sg < MT / 2; ++sg) {
+        bv[sg][0] = *(const float4v*)(bp + sg * 32);
+        bv[sg][1] = *(const float4v*)(bp + sg * 32 + 4);
+      }
+    }
     if (a.stamps && tile == lb) st2 = __builtin_amdgcn_s_memtime();
 
     // ---- epilogue of this tile (the next tile's first two stages are already in flight / landed)
@@ -635,6 +657,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       } else {
         if (a.act) conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, true, false>(acc, bv, yp, ystep, nullptr, 0);
         else conv_epilogue_fast<(MT >= 2 ? MT : 2), NT, false, false>(acc, bv, yp, ystep, nullptr, 0);
+        stores_pending = a.bias_lds > 0 && !(a.dbg & 512);   // (no other vector-memory instruction between these stores and the next wait)
       }
       if (a.stamps && tid == 0 && tile == lb) {   // diagnostic builds only (tools/stamps_igemm.py)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -745,10 +768,26 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   int grid_x = tiles_ch * tiles_px;
   // measured again after the fast epilogue: neutral for the 128x128 tile, 7-20 % faster for 1x1 layers on the
   // narrow channel tiles (proto.cv3 63 -> 51 us), so those run persistent
+  // round 2, with the biases in LDS and the counted wait after a tile's stores: in isolation the 128-channel 1x1 layers gain
+  // 3-10 % from the persistent walk once they have more tiles than resident blocks (tools/conv1_sweep.py: 39.2 -> 34.2,
+  // 47.4 -> 43.6, 21.1 -> 19.7 us), inside the network nothing (model.4.cv2 46.9 -> 47.8, model.15.cv2 37.9 -> 39.6 us):
+  // still one tile per block for them
   if ((a.dbg & 64) || (a.ksize == 1 && BCH <= 64 && !knobs().no_persist)) {
     int per_cu = (160 * 1024) / LDS;
     if (per_cu > 2) per_cu = 2;
     if (grid_x > g_num_cus * per_cu) grid_x = g_num_cus * per_cu;
+  }
+  // bias table in LDS: the 1x1 / 3x3 fast-epilogue launches without the fused second conv or the decode (their epilogues
+  // reuse the stage memory and read a.bias directly)
+  ConvArgs aa = a;
+  int lds_bytes = LDS;
+  {
+    const int nb = a.convt_co > 0 ? a.convt_co : tiles_ch * BCH;
+    const bool plain = !a.w2 && !a.dec_preds && !a.phase && !a.out_f32 && MT >= 2 && !knobs().no_bias_lds;
+    if (plain && nb * 4 <= 8192 && (a.w_rows == 0 || nb <= a.w_rows)) {
+      aa.bias_lds = nb;
+      lds_bytes += nb * 4;
+    }
   }
   const dim3 grid(grid_x), block(WCH * WPX * 64);
   hipError_t e;
@@ -756,11 +795,11 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   auto k2 = conv_igemm_kernel<MT, NT, WCH, WPX, 2>;
   auto k3 = conv_igemm_kernel<MT, NT, WCH, WPX, 3>;
   auto k = a.ksize == 1 ? k1 : (a.ksize == 2 ? k2 : k3);
-  if (LDS > 65536) {
-    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (lds_bytes > 65536) {
+    e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 8192);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k, grid, block, LDS, s, a);
+  hipLaunchKernelGGL(k, grid, block, lds_bytes, s, aa);
   return (int)hipGetLastError();
 }
 
@@ -773,6 +812,7 @@ const Knobs& knobs() {
     v.no_wide = getenv("M355_NO_WIDE") != nullptr;
     v.lean = getenv("M355_LEAN") != nullptr;
     v.no_m32 = getenv("M355_NO_M32") != nullptr;
+    v.no_bias_lds = getenv("M355_NO_BIAS_LDS") != nullptr;
     v.static_tiles = getenv("M355_STATIC_TILES") != nullptr;   // persistent kernels: static tile walk instead of the queue
     v.no_persist = getenv("M355_NO_PERSIST") != nullptr;
     v.stem_gather = getenv("M355_STEM_GATHER") != nullptr;

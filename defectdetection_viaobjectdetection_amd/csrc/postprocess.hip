@@ -4,6 +4,8 @@
 //
 // This file is compiled with -ffp-contract=off: the IoU / box arithmetic must round exactly like the
 // oracle's float32 numpy ops so that the NMS keep-set is bit-exact for identical inputs.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace m355 {
@@ -41,8 +43,11 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, in
   Box* kbox = (Box*)smem;
   int* kidx = (int*)(smem + MAX_KEEP * 16);
   int* misc = (int*)(smem + MAX_KEEP * 20);
-  unsigned long long* keys =
-      keys_in_lds ? (unsigned long long*)(smem + MAX_KEEP * 20 + 16) : gkeys + (long)blockIdx.x * npad_max;
+  // keys_in_lds = number of keys the LDS buffer holds (0: none).  The candidates are counted first; the sort runs in LDS when
+  // they fit and in the global workspace otherwise.  (Sizing the LDS buffer for EVERY anchor -- 128 KB at 8400 -- made this
+  // block need a whole CU: beside the forward kernels of the next batch it waited for one, 148 us instead of 50.)
+  unsigned long long* const lkeys = (unsigned long long*)(smem + MAX_KEEP * 20 + 16);
+  unsigned long long* const wkeys = gkeys + (long)blockIdx.x * npad_max;
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int wd = 4 + nc + nm;
@@ -56,11 +61,14 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, in
     for (int c = 1; c < nc; ++c) best = fmaxf(best, p[c]);
     if (best > conf_thr) {
       const int slot = atomicAdd(&misc[0], 1);
-      keys[slot] = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)a);
+      const unsigned long long key = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)a);
+      if (slot < keys_in_lds) lkeys[slot] = key;
+      if (gkeys) wkeys[slot] = key;           // (only read when the candidates overflow the LDS buffer)
     }
   }
   __syncthreads();
   const int n = misc[0];
+  unsigned long long* const keys = (n <= keys_in_lds || !gkeys) ? lkeys : wkeys;
   int npad = 1;
   while (npad < n) npad <<= 1;
   for (int i = n + tid; i < npad; i += NMS_THREADS) keys[i] = 0ull;
@@ -161,59 +169,95 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const float* preds, in
 //      thread turns 6 cells x 2 rows into 16 output pixels = one 16-byte store.
 // Detections whose box does not touch the tile's halo window get zero-filled without touching LDS.
 // ---------------------------------------------------------------------------------------------
-constexpr int MK_CELLS = 18 * 18;        // 324
-constexpr int MK_CELLS_PAD = 21 * 16;    // 336: whole 16-cell MFMA column blocks
-constexpr int MK_LG_PITCH = MK_CELLS_PAD + 4;
-
-template <int NM>
+// Tile = TR x TC prototype cells -> 4 TR x 4 TC output pixels.  8 x 32 (not 16 x 16): a row segment of the tile is then 128
+// output bytes = one whole cache line per 8 lanes (16 x 16 wrote 64-byte half lines: 1.67 TB/s of masks at batch 32, 22
+// detections per image); same number of cells per block, same LDS.
+template <int NM, int TR, int TC>
 __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, const int* counts, const half_t* protos,
                                                           int max_det, int mh, int mw, int in_h, int in_w,
-                                                          uint8_t* masks) {
+                                                          uint8_t* masks, int dbg) {
   static_assert(NM == 32, "one 64-byte NHWC prototype pixel = one MFMA K step");
-  __shared__ __attribute__((aligned(16))) half_t patch[MK_CELLS_PAD * NM];   // 21.5 KB
-  __shared__ __attribute__((aligned(16))) float lg[16 * MK_LG_PITCH];        // 21.8 KB
+  constexpr int PW = TC + 2, PH = TR + 2;               // patch with its 1-cell halo
+  constexpr int CELLS = PH * PW;
+  constexpr int CELLS_PAD = (CELLS + 15) / 16 * 16;     // whole 16-cell MFMA column blocks
+  constexpr int LG_PITCH = CELLS_PAD + 4;
+  constexpr int TPR = TC / 4;                           // threads per output row (16 pixels each)
+  static_assert(256 / TPR == 4 * TR, "one 16-byte store per thread covers the tile");
+  __shared__ __attribute__((aligned(16))) half_t patch[CELLS_PAD * NM];
+  __shared__ __attribute__((aligned(16))) float lg[16 * LG_PITCH];
   __shared__ __attribute__((aligned(16))) half_t cf_hi[16 * NM], cf_lo[16 * NM];
   __shared__ float bxs[16][4];
+  __shared__ short touch_list[MAX_KEEP];     // detections whose box touches this tile's halo window
+  __shared__ uint8_t touch_flag[MAX_KEEP];
+  __shared__ int ntouch_s;
   const int b = blockIdx.y;
   int n = counts[b];
   if (n > max_det) n = max_det;
   if (n <= 0) return;
-  const int tiles_x = (mw + 15) / 16;
+  const int tiles_x = (mw + TC - 1) / TC;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, g = lane >> 4;
   const float wr = (float)mw / (float)in_w, hr = (float)mh / (float)in_h;
+  // halo window of this tile in prototype-grid coordinates (for the box-touch test)
+  const float wx0 = (float)(tx * TC - 1), wx1 = (float)(tx * TC + TC), wy0 = (float)(ty * TR - 1),
+              wy1 = (float)(ty * TR + TR);
+  const int oy = tid / TPR, seg = tid - oy * TPR;
+  const int Y = ty * (4 * TR) + oy, X0 = tx * (4 * TC) + seg * 16;
+  const int qy = oy >> 2, ry = oy & 3;
+  const int r0 = (ry < 2) ? qy : qy + 1;
+  const float ly1 = (ry == 0) ? 0.625f : (ry == 1) ? 0.875f : (ry == 2) ? 0.125f : 0.375f;
+  const float ly0 = 1.f - ly1;
+
+  // 0. Which detections touch this tile?  Everything else in the tile is zeros: those stores need nothing but the boxes, so
+  //    they are issued first and drain while the patch / coefficient loads of the touching detections are in flight
+  //    (the kernel was bound by its load -> barrier -> MFMA -> barrier chain per 16 detections, not by the stores:
+  //    68 of 107 us with the stores and the upsample switched off).
+  if (tid == 0) ntouch_s = 0;
+  __syncthreads();
+  for (int d = tid; d < n; d += 256) {
+    const float* dp = dets + ((long)b * max_det + d) * (6 + NM);
+    const float x1 = dp[0] * wr, y1 = dp[1] * hr, x2 = dp[2] * wr, y2 = dp[3] * hr;
+    const bool touches = !(dbg & 1) && !(wx1 < x1 || wx0 >= x2 || wy1 < y1 || wy0 >= y2);
+    touch_flag[d] = touches ? 1 : 0;
+    if (touches) touch_list[atomicAdd(&ntouch_s, 1)] = (short)d;   // (order is irrelevant: every detection's mask is independent)
+  }
+  __syncthreads();
+  const int nt = ntouch_s;
+  if (Y < in_h && !(dbg & 2)) {
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    for (int d = 0; d < n; ++d) {
+      if (touch_flag[d]) continue;
+      uint8_t* mp = masks + (((long)b * max_det + d) * in_h + Y) * in_w + X0;
+      if (X0 + 16 <= in_w) {
+        __builtin_nontemporal_store(uint4v{0u, 0u, 0u, 0u}, (uint4v*)mp);
+      } else {
+        for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = 0;
+      }
+    }
+  }
+  if (nt == 0) return;
   // 1. prototype patch (4 x 16-byte chunks per cell)
   const half_t* pb = protos + (long)b * mh * mw * NM;
-  for (int i = tid; i < MK_CELLS_PAD * 4; i += 256) {
+  for (int i = tid; i < CELLS_PAD * 4; i += 256) {
     const int cell = i >> 2, ch = i & 3;
     half8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (cell < MK_CELLS) {
-      const int ly = cell / 18, lx = cell - ly * 18;
-      int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
+    if (cell < CELLS) {
+      const int ly = cell / PW, lx = cell - ly * PW;
+      int y = ty * TR - 1 + ly, x = tx * TC - 1 + lx;
       y = y < 0 ? 0 : (y >= mh ? mh - 1 : y);
       x = x < 0 ? 0 : (x >= mw ? mw - 1 : x);
       v = *(const half8*)(pb + ((long)y * mw + x) * NM + ch * 8);
     }
     *(half8*)(patch + cell * NM + ch * 8) = v;
   }
-  // halo window of this tile in prototype-grid coordinates (for the box-touch test)
-  const float wx0 = (float)(tx * 16 - 1), wx1 = (float)(tx * 16 + 16), wy0 = (float)(ty * 16 - 1),
-              wy1 = (float)(ty * 16 + 16);
-  const int oy = tid >> 2, seg = tid & 3;
-  const int Y = ty * 64 + oy, X0 = tx * 64 + seg * 16;
-  const int qy = oy >> 2, ry = oy & 3;
-  const int r0 = (ry < 2) ? qy : qy + 1;
-  const float ly1 = (ry == 0) ? 0.625f : (ry == 1) ? 0.875f : (ry == 2) ? 0.125f : 0.375f;
-  const float ly0 = 1.f - ly1;
-
-  for (int c0 = 0; c0 < n; c0 += 16) {
-    const int nd = (n - c0 < 16) ? (n - c0) : 16;
+  for (int c0 = 0; c0 < nt; c0 += 16) {
+    const int nd = (nt - c0 < 16) ? (nt - c0) : 16;
     __syncthreads();  // previous chunk's readers of lg / cf / bxs are done (and the patch is complete)
     // 2a. coefficients (hi + lo fp16) and scaled boxes of this chunk
     for (int i = tid; i < 16 * NM; i += 256) {
       const int d = i / NM, k = i - d * NM;
-      const float c = d < nd ? dets[((long)b * max_det + c0 + d) * (6 + NM) + 6 + k] : 0.f;
+      const float c = d < nd ? dets[((long)b * max_det + touch_list[c0 + d]) * (6 + NM) + 6 + k] : 0.f;
       const half_t hi = (half_t)c;
       cf_hi[i] = hi;
       cf_lo[i] = (half_t)(c - (float)hi);
@@ -221,7 +265,7 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
     if (tid < 64) {
       const int d = tid >> 2, f = tid & 3;
       float v = 0.f;
-      if (d < nd) v = dets[((long)b * max_det + c0 + d) * (6 + NM) + f] * ((f & 1) ? hr : wr);
+      if (d < nd) v = dets[((long)b * max_det + touch_list[c0 + d]) * (6 + NM) + f] * ((f & 1) ? hr : wr);
       bxs[d][f] = v;
     }
     __syncthreads();
@@ -229,14 +273,14 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
     {
       const half8 a_hi = *(const half8*)(cf_hi + l15 * NM + g * 8);
       const half8 a_lo = *(const half8*)(cf_lo + l15 * NM + g * 8);
-      for (int t = wave; t < MK_CELLS_PAD / 16; t += 4) {
+      for (int t = wave; t < CELLS_PAD / 16; t += 4) {
         const int cell = t * 16 + l15;
         const half8 bf = *(const half8*)(patch + cell * NM + g * 8);
         float4v acc = {0.f, 0.f, 0.f, 0.f};
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_hi, bf, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_lo, bf, acc, 0, 0, 0);
-        const int ly = cell / 18, lx = cell - ly * 18;
-        int y = ty * 16 - 1 + ly, x = tx * 16 - 1 + lx;
+        const int ly = cell / PW, lx = cell - ly * PW;
+        int y = ty * TR - 1 + ly, x = tx * TC - 1 + lx;
         y = y < 0 ? 0 : (y >= mh ? mh - 1 : y);
         x = x < 0 ? 0 : (x >= mw ? mw - 1 : x);
         const float xf = (float)x, yf = (float)y;
@@ -244,7 +288,7 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
         for (int j = 0; j < 4; ++j) {
           const int d = g * 4 + j;
           const bool in = xf >= bxs[d][0] && xf < bxs[d][2] && yf >= bxs[d][1] && yf < bxs[d][3];
-          lg[d * MK_LG_PITCH + cell] = in ? acc[j] : 0.f;
+          lg[d * LG_PITCH + cell] = in ? acc[j] : 0.f;
         }
       }
     }
@@ -252,13 +296,12 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
     // 3. upsample + threshold + store, one detection after the other (no barrier in between)
     if (Y < in_h) {
       for (int d = 0; d < nd; ++d) {
-        const bool touches = !(wx1 < bxs[d][0] || wx0 >= bxs[d][2] || wy1 < bxs[d][1] || wy0 >= bxs[d][3]);
         uint8_t o[16];
-        if (touches) {
-          const float* l0 = lg + d * MK_LG_PITCH + r0 * 18 + seg * 4;
+        {
+          const float* l0 = lg + d * LG_PITCH + r0 * PW + seg * 4;
           float cv[6];
 #pragma unroll
-          for (int c = 0; c < 6; ++c) cv[c] = ly0 * l0[c] + ly1 * l0[18 + c];
+          for (int c = 0; c < 6; ++c) cv[c] = ly0 * l0[c] + ly1 * l0[PW + c];
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const float a0 = cv[q], a1 = cv[q + 1], a2 = cv[q + 2];
@@ -267,13 +310,12 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
             o[q * 4 + 2] = (0.875f * a1 + 0.125f * a2) > 0.f ? 1 : 0;
             o[q * 4 + 3] = (0.625f * a1 + 0.375f * a2) > 0.f ? 1 : 0;
           }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) o[j] = 0;
         }
-        uint8_t* mp = masks + (((long)b * max_det + c0 + d) * in_h + Y) * in_w + X0;
+        uint8_t* mp = masks + (((long)b * max_det + touch_list[c0 + d]) * in_h + Y) * in_w + X0;
+        if (dbg & 2) continue;
         if (X0 + 16 <= in_w) {
-          *(uint4*)mp = *(const uint4*)o;
+          typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+          __builtin_nontemporal_store(*(const uint4v*)o, (uint4v*)mp);   // written once, never read by the GPU again
         } else {
           for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = o[j];
         }
@@ -296,9 +338,16 @@ int launch_nms(const float* preds, int B, int A, int nc, int nm, float conf, flo
   int npad = 1;
   while (npad < A) npad <<= 1;
   const size_t base = MAX_KEEP * 20 + 16;
-  const bool in_lds = base + (size_t)npad * 8 <= 160 * 1024 - 256;
-  if (!in_lds && workspace_bytes < (size_t)B * npad * 8) return -1;
-  const size_t lds = in_lds ? base + (size_t)npad * 8 : base;
+  // LDS for 4096 keys (32 KB; a power of two, the bitonic network's padding) when a global workspace exists for the
+  // overflow, for every anchor otherwise
+  const bool have_ws = workspace && workspace_bytes >= (size_t)B * npad * 8;
+  int lds_keys = npad;
+  if (have_ws && lds_keys > 4096) lds_keys = 4096;
+  if (base + (size_t)lds_keys * 8 > 160 * 1024 - 256) {
+    if (!have_ws) return -1;
+    lds_keys = 4096;
+  }
+  const size_t lds = base + (size_t)lds_keys * 8;
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)nms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -307,7 +356,7 @@ int launch_nms(const float* preds, int B, int A, int nc, int nm, float conf, flo
     attr_set = true;
   }
   hipLaunchKernelGGL(nms_kernel, dim3(B), dim3(NMS_THREADS), lds, s, preds, A, nc, nm, conf, iou, max_det, dets,
-                     counts, (unsigned long long*)workspace, in_lds ? 1 : 0, npad);
+                     counts, have_ws ? (unsigned long long*)workspace : nullptr, lds_keys, npad);
   return (int)hipGetLastError();
 }
 
@@ -315,9 +364,17 @@ int launch_proto_masks(const float* dets, const int* counts, const half_t* proto
                        int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s) {
   if (nm != 32) return -1;
   if (in_h % mh || in_w % mw || in_w / mw != 4 || in_h / mh != 4 || in_w % 16) return -1;
-  const int tiles = ((mw + 15) / 16) * ((mh + 15) / 16);
-  hipLaunchKernelGGL(proto_masks_kernel<32>, dim3(tiles, B), dim3(256), 0, s, dets, counts, protos, max_det, mh, mw,
-                     in_h, in_w, masks);
+  static const int dbg = getenv("M355_MASK_DBG") ? atoi(getenv("M355_MASK_DBG")) : 0;   // timing ablations: 1 zero fill only, 2 no stores
+  static const int shape = getenv("M355_MASK_TILE") ? atoi(getenv("M355_MASK_TILE")) : 0;   // 1: the 16 x 16-cell tile (experiments)
+  if (shape == 1) {
+    const int tiles = ((mw + 15) / 16) * ((mh + 15) / 16);
+    hipLaunchKernelGGL((proto_masks_kernel<32, 16, 16>), dim3(tiles, B), dim3(256), 0, s, dets, counts, protos, max_det, mh, mw,
+                       in_h, in_w, masks, dbg);
+  } else {
+    const int tiles = ((mw + 31) / 32) * ((mh + 7) / 8);
+    hipLaunchKernelGGL((proto_masks_kernel<32, 8, 32>), dim3(tiles, B), dim3(256), 0, s, dets, counts, protos, max_det, mh, mw,
+                       in_h, in_w, masks, dbg);
+  }
   return (int)hipGetLastError();
 }
 

@@ -1,0 +1,8 @@
+#!/bin/bash
+# 1x1 sweep under rocprofv3 (run through gpurun from the repo root); result in gpurun_out/conv1_sweep.txt
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/conv1_sweep; rm -rf $O; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --output-format csv -d $O -o t -- python3 $R/tools/conv1_sweep.py > $O/run.log 2>&1 || { tail -5 $O/run.log; exit 1; }
+python3 $R/tools/conv1_sweep.py --parse $(find $O -name "t_kernel_trace.csv") > $R/gpurun_out/conv1_sweep.txt
+find $O -name "*.csv" -delete
+cat $R/gpurun_out/conv1_sweep.txt

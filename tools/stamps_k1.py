@@ -17,7 +17,7 @@ def run(B, H, W, cin, cout, k, stride, tile, reps=2):
     span = (s[:, 5].max() - s[:, 4].min()) / 100e6
     nk = (cin * k * k + 63) // 64
     print(f"B={B} {(H, W, cin, cout, k, stride)}: blocks {len(s)} span {span * 1e6:.1f} us; prologue {np.median(pro):.0f} K loop {np.median(main):.0f} ({np.median(main) / nk:.0f}/step) epilogue {np.median(epi):.0f} total {np.median(tot):.0f}")
-for B in (2, 8, 32):
-    run(B, 80, 80, 384, 128, 1, 1, 0)
-for B in (2, 8, 32):
-    run(B, 40, 40, 768, 256, 1, 1, 0)
+shapes = [(80, 80, 384, 128), (80, 80, 192, 128), (80, 80, 128, 128), (40, 40, 768, 256), (40, 40, 256, 256), (40, 40, 384, 256),
+          (20, 20, 512, 512), (20, 20, 768, 512), (20, 20, 512, 256), (20, 20, 1024, 512), (160, 160, 96, 64), (160, 160, 64, 64)]
+for (H, W, ci, co) in shapes:
+    run(32, H, W, ci, co, 1, 1, -1 if len(sys.argv) < 2 else int(sys.argv[1]))
