@@ -366,6 +366,37 @@ class TrainEngine:
     def _gview(self, sl: Slice) -> torch.Tensor:
         return self.gtensors[sl.t][..., sl.off:sl.off + sl.c]
 
+    def _uncovered(self, written, sl: Slice):
+        """Channel intervals of a gradient slice nobody has written yet in this backward."""
+        lo, hi = sl.off, sl.off + sl.c
+        out, cur = [], lo
+        for a, b in sorted(iv for iv in written.get(sl.t, []) if iv[0] < hi and iv[1] > lo):
+            if a > cur:
+                out.append((cur, a))
+            cur = max(cur, b)
+        if cur < hi:
+            out.append((cur, hi))
+        return out
+
+    def _claim(self, written, sl: Slice) -> bool:
+        """True when nothing of this gradient slice has been written yet: the caller STORES its contribution instead of
+        accumulating it (no zero fill of the gradient buffers -- 100 fill kernels, 1.1 ms of a 46 ms step -- and the first
+        dgrad into a slice does not read zeros back as its residual).  A partly written slice has its unwritten channels
+        zeroed and accumulates."""
+        gaps = self._uncovered(written, sl)
+        first = gaps == [(sl.off, sl.off + sl.c)]
+        if not first:
+            for a, b in gaps:
+                self.gtensors[sl.t][..., a:b].zero_()
+        written.setdefault(sl.t, []).append((sl.off, sl.off + sl.c))
+        return first
+
+    def _ensure(self, written, sl: Slice) -> None:
+        """A gradient slice about to be READ: channels no consumer wrote (none in the graphs built here) are zero."""
+        for a, b in self._uncovered(written, sl):
+            self.gtensors[sl.t][..., a:b].zero_()
+        written.setdefault(sl.t, []).append((sl.off, sl.off + sl.c))
+
     def backward(self, d_raw: torch.Tensor, d_protos: torch.Tensor, on_ready=None) -> None:
         """d_raw (B,A,64+nc+32) fp32, d_protos (B,H/4,W/4,32): gradients of the loss w.r.t. forward()'s outputs.
         Fills ``self.grads`` (fp32, parameter layout).  ``on_ready(name)`` is called once the kernels producing that
@@ -375,9 +406,9 @@ class TrainEngine:
         for i, t in enumerate(self.tensors):
             if self.gtensors[i] is None:
                 self.gtensors[i] = torch.zeros_like(t)
-            else:
-                self.gtensors[i].zero_()
+        written: Dict[int, list] = {}                                     # tensor -> channel intervals written in this backward
         self.gtensors[self.protos_t].copy_(d_protos.to(torch.float16))
+        written[self.protos_t] = [(0, self.tensors[self.protos_t].shape[-1])]
         ready: List[str] = []
         for op in reversed(self.ops):
             if on_ready is not None:                                        # gradients finished by the previous op
@@ -393,8 +424,12 @@ class TrainEngine:
                 hi, wi = tin.shape[1:3]
                 ho, wo = tout.shape[1:3]
                 cout, cin = dst.c, src.c
+                self._ensure(written, dst)
                 if op["res"] is not None:                                   # y = act(bn(z)) + res
-                    self._gview(op["res"]).add_(self._gview(dst))
+                    if self._claim(written, op["res"]):
+                        self._gview(op["res"]).copy_(self._gview(dst))
+                    else:
+                        self._gview(op["res"]).add_(self._gview(dst))
                 dyp, _, lddy = self._slice_ptr(self.gtensors, dst)
                 if "dz" not in sv:
                     sv["dz"] = torch.empty_like(sv["z"])
@@ -418,8 +453,9 @@ class TrainEngine:
                     self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, cin, ho, wo, cout, s.k,
                                        s.stride, s.k // 2, gw)
                     gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
+                    acc = 0 if self._claim(written, src) else gp
                     self._conv_launch(sv["dz"].data_ptr(), ho * wo * cout, cout, ho, wo, cout, self.packed[name + ":dgrad"],
-                                      gp, gbs, ldg, hi, wi, cin, s.k, 1, s.k // 2, res_ptr=gp, r_bs=gbs, ldr=ldg,
+                                      gp, gbs, ldg, hi, wi, cin, s.k, 1, s.k // 2, res_ptr=acc, r_bs=gbs, ldr=ldg,
                                       tmode=1 if s.stride == 2 else 0)
             elif kind == "plain":
                 name, src = op["name"], op["src"]
@@ -436,14 +472,16 @@ class TrainEngine:
                 self.grads[f"{name}.weight"].copy_(dw[:cout])
                 ready += [f"{name}.bias", f"{name}.weight"]
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
+                acc = 0 if self._claim(written, src) else gp
                 self._conv_launch(dz.data_ptr(), h * w * cp, cp, h, w, cp, self.packed[name + ":dgrad"], gp, gbs, ldg, h, w,
-                                  src.c, 1, 1, 0, res_ptr=gp, r_bs=gbs, ldr=ldg)
+                                  src.c, 1, 1, 0, res_ptr=acc, r_bs=gbs, ldr=ldg)
                 op["_dz_keepalive"] = (dz, dw)
             elif kind == "convt":
                 name, src, dst = op["name"], op["src"], op["dst"]
                 tin = self.tensors[src.t]
                 h, w = tin.shape[1:3]
                 cin, cout = src.c, dst.c
+                self._ensure(written, dst)
                 gy = self.gtensors[dst.t]                                   # (B, 2h, 2w, cout) contiguous, own tensor
                 self.grads[f"{name}.bias"].copy_(gy.float().sum((0, 1, 2)))
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
@@ -453,12 +491,14 @@ class TrainEngine:
                 self.grads[f"{name}.weight"].copy_(dw.permute(0, 3, 1, 2))
                 ready += [f"{name}.bias", f"{name}.weight"]
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
+                acc = 0 if self._claim(written, src) else gp
                 self._conv_launch(gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, self.packed[name + ":dgrad"], gp,
-                                  gbs, ldg, h, w, cin, 2, 2, 0, res_ptr=gp, r_bs=gbs, ldr=ldg)
+                                  gbs, ldg, h, w, cin, 2, 2, 0, res_ptr=acc, r_bs=gbs, ldr=ldg)
                 op["_dw_keepalive"] = dw
             elif kind == "pool":                                           # SPPF: y1 = mp(a), y2 = mp(y1), y3 = mp(y2)
                 src, dst = op["src"], op["dst"]
                 c = src.c
+                self._ensure(written, Slice(dst.t, dst.off, 3 * c))
                 # contiguous NCHW copies: on the permuted (channels-last) views torch picks max_pool_backward_nhwc, 0.6 ms a call
                 a = self.tensors[src.t][..., src.off:src.off + c].permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)
                 y1 = F.max_pool2d(a, 5, 1, 2)
@@ -466,12 +506,20 @@ class TrainEngine:
                 y3 = F.max_pool2d(y2, 5, 1, 2)
                 g = self.gtensors[dst.t][..., dst.off:dst.off + 3 * c].permute(0, 3, 1, 2).float().contiguous()
                 (ga,) = torch.autograd.grad((y1, y2, y3), a, (g[:, :c], g[:, c:2 * c], g[:, 2 * c:]))
-                self._gview(src).add_(ga.permute(0, 2, 3, 1).half())
+                if self._claim(written, src):
+                    self._gview(src).copy_(ga.permute(0, 2, 3, 1))
+                else:
+                    self._gview(src).add_(ga.permute(0, 2, 3, 1).half())
             elif kind == "up":
                 src, dst = op["src"], op["dst"]
+                self._ensure(written, dst)
                 g = self._gview(dst)
                 Bq, H2, W2, c = g.shape
-                self._gview(src).add_(g.reshape(Bq, H2 // 2, 2, W2 // 2, 2, c).float().sum((2, 4)).half())
+                gs = g.reshape(Bq, H2 // 2, 2, W2 // 2, 2, c).float().sum((2, 4))
+                if self._claim(written, src):
+                    self._gview(src).copy_(gs)
+                else:
+                    self._gview(src).add_(gs.half())
         if on_ready is not None:
             for k in ready:
                 on_ready(k)
