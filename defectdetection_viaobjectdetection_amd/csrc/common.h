@@ -134,6 +134,8 @@ int launch_stem(const StemArgs& a, hipStream_t s);
 
 int launch_sppf_pool(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy,
                      int B, int H, int W, int C, hipStream_t s);
+int launch_sppf_pool_bwd(const half_t* a, long a_bs, int lda, const half_t* y, long y_bs, int ldy, const half_t* gy, long gy_bs,
+                         int ldgy, half_t* ga, long ga_bs, int ldga, int B, int H, int W, int C, int accumulate, hipStream_t s);
 int launch_upsample2x(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy,
                       int B, int H, int W, int C, hipStream_t s);
 // ADown's pooling (yolov9c): a = avg_pool2d(x, 2, 1, 0)[..., :C/2] (H-1 x W-1), m = max_pool2d(avg_pool2d(x, 2, 1, 0)[..., C/2:], 3, 2, 1) (H/2 x W/2)

@@ -1752,6 +1752,15 @@ int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "sppf launch failed: " + std::to_string(rc));
 }
 
+int m355_sppf_pool_bwd_launch(const void* a, int64_t a_bstride, int32_t lda, const void* y, int64_t y_bstride, int32_t ldy,
+                              const void* gy, int64_t gy_bstride, int32_t ldgy, void* ga, int64_t ga_bstride, int32_t ldga,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream) {
+  if (!a || !y || !gy || !ga) return set_err(M355_ERR_INVALID, "null pointer");
+  const int rc = launch_sppf_pool_bwd((const half_t*)a, a_bstride, lda, (const half_t*)y, y_bstride, ldy, (const half_t*)gy, gy_bstride,
+                                      ldgy, (half_t*)ga, ga_bstride, ldga, B, H, W, C, accumulate, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "sppf backward launch failed: " + std::to_string(rc));
+}
+
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

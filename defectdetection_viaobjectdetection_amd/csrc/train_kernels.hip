@@ -449,4 +449,100 @@ int launch_grad_sumsq(const float* g, long n, float* out, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Backward of SPPF's pooling chain y1 = mp5(a), y2 = mp5(y1), y3 = mp5(y2) (MaxPool2d(5, 1, 2); SURVEY A13, upstream reaches
+// it through autograd of F.max_pool2d).  The training step ran it as three torch max_pool2d forward + backward pairs on
+// fp32 NCHW copies (1.2 ms of a 44 ms step).  One block per (image, 8-channel group): the whole map of those channels lives
+// in LDS.  Per stage: the argmax of every window (first maximum in row-major order, torch's rule), then a GATHER -- position
+// p sums the incoming gradient of the windows whose argmax is p, in ascending (row, column) order of the windows -- so
+// there are no atomics and the result is bitwise reproducible.  gy (B,H,W,>=3C): gradients of [y1 | y2 | y3]; ga receives
+// d(loss)/da, stored or accumulated (fp16).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const half_t* a, long a_bs, int lda, const half_t* y, long y_bs, int ldy,
+                                                            const half_t* gy, long gy_bs, int ldgy, half_t* ga, long ga_bs,
+                                                            int ldga, int H, int W, int C, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = H * W * 8;
+  half_t* v = (half_t*)smem;                       // [px][8] values of the stage's input map
+  unsigned short* idx = (unsigned short*)(v + n);  // [window][8] argmax pixel of every window
+  float* rout = (float*)(idx + n);                 // [px][8] gradient w.r.t. the stage's OUTPUT map
+  float* rin = rout + n;                           // [px][8] gradient w.r.t. the stage's INPUT map
+  const int groups = C / 8;
+  const int b = blockIdx.x / groups, c0 = (blockIdx.x - b * groups) * 8;
+  const half_t* ab = a + (long)b * a_bs + c0;
+  const half_t* yb = y + (long)b * y_bs + c0;
+  const half_t* gb = gy + (long)b * gy_bs + c0;
+  for (int i = threadIdx.x; i < H * W; i += 256) {           // gradient of y3
+    const half8 g3 = *(const half8*)(gb + (long)i * ldgy + 2 * C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rout[i * 8 + j] = (float)g3[j];
+  }
+  for (int stage = 2; stage >= 0; --stage) {
+    const half_t* src = stage == 2 ? yb + C : (stage == 1 ? yb : ab);       // y2, y1, a
+    const int lds_ = stage == 0 ? lda : ldy;
+    for (int i = threadIdx.x; i < H * W; i += 256) *(half8*)(v + i * 8) = *(const half8*)(src + (long)i * lds_);
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) {             // argmax of the window centred on pixel q
+      const int q = e >> 3, ch = e & 7;
+      const int qy = q / W, qx = q - qy * W;
+      const int y0 = qy - 2 < 0 ? 0 : qy - 2, y1 = qy + 2 >= H ? H - 1 : qy + 2;
+      const int x0 = qx - 2 < 0 ? 0 : qx - 2, x1 = qx + 2 >= W ? W - 1 : qx + 2;
+      float best = -INFINITY;
+      int bi = y0 * W + x0;
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+          const float t = (float)v[(yy * W + xx) * 8 + ch];
+          if (t > best) { best = t; bi = yy * W + xx; }
+        }
+      idx[e] = (unsigned short)bi;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n; e += 256) {             // gather
+      const int p = e >> 3, ch = e & 7;
+      const int py = p / W, px = p - py * W;
+      const int y0 = py - 2 < 0 ? 0 : py - 2, y1 = py + 2 >= H ? H - 1 : py + 2;
+      const int x0 = px - 2 < 0 ? 0 : px - 2, x1 = px + 2 >= W ? W - 1 : px + 2;
+      float sum = 0.f;
+      for (int yy = y0; yy <= y1; ++yy)
+        for (int xx = x0; xx <= x1; ++xx) {
+          const int q = yy * W + xx;
+          if (idx[q * 8 + ch] == (unsigned short)p) sum += rout[q * 8 + ch];
+        }
+      if (stage > 0) sum += (float)gb[(long)p * ldgy + (stage - 1) * C + ch];   // the map's own slot in the concat: y2 (stage 2), y1 (stage 1)
+      rin[e] = sum;
+    }
+    __syncthreads();
+    float* t = rout; rout = rin; rin = t;
+  }
+  half_t* gab = ga + (long)b * ga_bs + c0;
+  for (int i = threadIdx.x; i < H * W; i += 256) {
+    half8 o;
+    if (accumulate) {
+      const half8 old = *(const half8*)(gab + (long)i * ldga);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = m355_to_half((float)old[j] + (float)m355_to_half(rout[i * 8 + j]));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = m355_to_half(rout[i * 8 + j]);
+    }
+    *(half8*)(gab + (long)i * ldga) = o;
+  }
+}
+}  // namespace
+
+int launch_sppf_pool_bwd(const half_t* a, long a_bs, int lda, const half_t* y, long y_bs, int ldy, const half_t* gy, long gy_bs,
+                         int ldgy, half_t* ga, long ga_bs, int ldga, int B, int H, int W, int C, int accumulate, hipStream_t s) {
+  if (C % 8 || lda % 8 || ldy % 8 || ldgy % 8 || ldga % 8 || H * W > 65535) return -1;
+  const size_t lds = (size_t)H * W * 8 * (2 + 2 + 4 + 4);
+  if (lds > 160 * 1024) return -1;
+  if (lds > 65536) {
+    hipError_t e = hipFuncSetAttribute((const void*)sppf_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(sppf_pool_bwd_kernel, dim3(B * (C / 8)), dim3(256), lds, s, a, a_bs, lda, y, y_bs, ldy, gy, gy_bs, ldgy, ga,
+                     ga_bs, ldga, H, W, C, accumulate);
+  return (int)hipGetLastError();
+}
+
 }  // namespace m355

@@ -499,17 +499,26 @@ class TrainEngine:
                 src, dst = op["src"], op["dst"]
                 c = src.c
                 self._ensure(written, Slice(dst.t, dst.off, 3 * c))
-                # contiguous NCHW copies: on the permuted (channels-last) views torch picks max_pool_backward_nhwc, 0.6 ms a call
-                a = self.tensors[src.t][..., src.off:src.off + c].permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)
-                y1 = F.max_pool2d(a, 5, 1, 2)
-                y2 = F.max_pool2d(y1, 5, 1, 2)
-                y3 = F.max_pool2d(y2, 5, 1, 2)
-                g = self.gtensors[dst.t][..., dst.off:dst.off + 3 * c].permute(0, 3, 1, 2).float().contiguous()
-                (ga,) = torch.autograd.grad((y1, y2, y3), a, (g[:, :c], g[:, c:2 * c], g[:, 2 * c:]))
-                if self._claim(written, src):
-                    self._gview(src).copy_(ga.permute(0, 2, 3, 1))
-                else:
-                    self._gview(src).add_(ga.permute(0, 2, 3, 1).half())
+                hp, wp = self.tensors[src.t].shape[1:3]
+                first = self._claim(written, src)
+                if hp * wp * 96 <= 160 * 1024:                              # the map of 8 channels fits one block's LDS
+                    ap, abs_, lda = self._slice_ptr(self.tensors, src)
+                    yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
+                    gyp, gybs, ldgy = self._slice_ptr(self.gtensors, dst)
+                    gap, gabs, ldga = self._slice_ptr(self.gtensors, src)
+                    check(lib.m355_sppf_pool_bwd_launch(ap, abs_, lda, yp, ybs, ldy, gyp, gybs, ldgy, gap, gabs, ldga, B, hp, wp, c,
+                                                        0 if first else 1, st))
+                else:   # larger maps (network input > 1300 px): torch's pooling on contiguous NCHW fp32 copies
+                    a = self.tensors[src.t][..., src.off:src.off + c].permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)
+                    y1 = F.max_pool2d(a, 5, 1, 2)
+                    y2 = F.max_pool2d(y1, 5, 1, 2)
+                    y3 = F.max_pool2d(y2, 5, 1, 2)
+                    g = self.gtensors[dst.t][..., dst.off:dst.off + 3 * c].permute(0, 3, 1, 2).float().contiguous()
+                    (ga,) = torch.autograd.grad((y1, y2, y3), a, (g[:, :c], g[:, c:2 * c], g[:, 2 * c:]))
+                    if first:
+                        self._gview(src).copy_(ga.permute(0, 2, 3, 1))
+                    else:
+                        self._gview(src).add_(ga.permute(0, 2, 3, 1).half())
             elif kind == "up":
                 src, dst = op["src"], op["dst"]
                 self._ensure(written, dst)

@@ -215,6 +215,12 @@ int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_
                              void* dz, int32_t lddz, float* dbeta_dgamma, float* ws, void* stream);
 int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* Backward of the SPPF pooling chain (autograd of three F.max_pool2d(5, 1, 2) upstream): a = the pooled input slice, y = the
+ * forward concat slice [y1 | y2 | y3] (3C channels), gy = its gradient, ga = d(loss)/da stored (accumulate = 0) or added to
+ * what ga holds (fp16).  Gather formulation, no atomics: bitwise reproducible.  H * W * 96 bytes of LDS (<= 160 KB). */
+int m355_sppf_pool_bwd_launch(const void* a, int64_t a_bstride, int32_t lda, const void* y, int64_t y_bstride, int32_t ldy,
+                              const void* gy, int64_t gy_bstride, int32_t ldgy, void* ga, int64_t ga_bstride, int32_t ldga,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream);
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 

@@ -131,3 +131,27 @@ def test_conv2d_wgrad(case, cuda_device):
                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
     assert torch.equal(d_dw, d_dw2)
+
+
+@pytest.mark.parametrize("B,H,W,Cc,acc", [(3, 20, 20, 32, 0), (2, 13, 17, 16, 1), (2, 5, 4, 8, 0)])
+def test_sppf_pool_backward_matches_autograd(B, H, W, Cc, acc, cuda_device):
+    """The gather kernel against torch autograd through three F.max_pool2d(5, 1, 2) on the same fp16 values.
+    Quantised inputs force many exact ties inside the windows: the argmax rule (first maximum in row-major order) matters."""
+    from defectdetection_viaobjectdetection_amd import _capi as capi
+    g = torch.Generator().manual_seed(5)
+    a16 = (torch.randn((B, H, W, Cc), generator=g) * 2).round().div(2).half()            # values on a 0.5 grid: ties everywhere
+    a = a16.float().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+    y1 = F.max_pool2d(a, 5, 1, 2); y2 = F.max_pool2d(y1, 5, 1, 2); y3 = F.max_pool2d(y2, 5, 1, 2)
+    gy16 = torch.randn((B, H, W, 3 * Cc), generator=g).half()
+    gyn = gy16.float().permute(0, 3, 1, 2)
+    (ga_ref,) = torch.autograd.grad((y1, y2, y3), a, (gyn[:, :Cc], gyn[:, Cc:2 * Cc], gyn[:, 2 * Cc:]))
+    ga_ref = ga_ref.permute(0, 2, 3, 1)
+    ycat = torch.cat((y1, y2, y3), 1).permute(0, 2, 3, 1).half().contiguous()
+    old = torch.randn((B, H, W, Cc), generator=g).half()
+    d_a, d_y, d_gy, d_ga = a16.to(cuda_device), ycat.to(cuda_device), gy16.to(cuda_device), old.clone().to(cuda_device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    capi.check(capi.lib.m355_sppf_pool_bwd_launch(_p(d_a), H * W * Cc, Cc, _p(d_y), H * W * 3 * Cc, 3 * Cc, _p(d_gy), H * W * 3 * Cc, 3 * Cc,
+                                                  _p(d_ga), H * W * Cc, Cc, B, H, W, Cc, acc, st))
+    torch.cuda.synchronize()
+    want = (old.float() + ga_ref.half().float()).half() if acc else ga_ref.half()
+    assert torch.equal(d_ga.cpu(), want), float((d_ga.cpu().float() - want.float()).abs().max())
