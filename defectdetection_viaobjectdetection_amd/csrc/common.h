@@ -150,8 +150,13 @@ int launch_proto_masks(const float* dets, const int* counts, const half_t* proto
                        int nm, int mh, int mw, int in_h, int in_w, uint8_t* masks, hipStream_t s);
 
 // weight gradient (conv_wgrad.hip): dw fp32 [Cout][k*k*Cin] (KRSC).  Split-K partial slabs go to the caller's workspace
-// (conv_wgrad_workspace_bytes) and are added in split order: bitwise reproducible.  -3: workspace missing / too small.
+// (conv_wgrad_workspace_bytes) and are added in a fixed order: bitwise reproducible.  -3: workspace missing / too small.
 size_t conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int ksize);
+// 3x3 / stride-1 layers from spatial patches (conv_wgrad3.hip); launch_conv_wgrad routes to it and adds the slabs
+bool conv_wgrad3_ok(int B, int H, int W, int Cin, int Cout, int ksize, int stride, int pad, int lddz, int ldx);
+size_t conv_wgrad3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
+int launch_conv_wgrad3(const half_t* dz, long dz_bs, int lddz, const half_t* x, long x_bs, int ldx, int B, int H, int W, int Cin,
+                       int Cout, float* dw, const half_t* zero, float* ws, size_t ws_bytes, int* splitk, hipStream_t s);
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
                       int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
                       const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s);

@@ -15,7 +15,7 @@
 // Block = 128 co x 128 n output tile, 4 waves (64 x 64 each, 16 accumulator tiles), K step = 64 pixels, two
 // LDS stages; the pixel axis is split across blocks (split-K).  DETERMINISTIC reduction: every split writes its partial
 // tile with plain stores into its own slab of a caller-provided workspace ([splitk][Cout][N] fp32) and a second kernel
-// adds the slabs in split order -- bitwise reproducible gradients (float atomics made two runs of one batch differ, and
+// adds the slabs in a fixed order (wgrad_reduce_kernel) -- bitwise reproducible gradients (float atomics made two runs of one batch differ, and
 // a 60-layer fp16-storage backward amplifies such last-bit differences to 1e-2 in the early layers: DESIGN.md section 8).
 // One split (small layers): the tile goes straight to dW.
 #include <stdlib.h>
@@ -185,23 +185,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// dW[i] = ws[0][i] + ws[1][i] + ... in split order (fixed association: bitwise reproducible)
+// dW[i] = sum over the splits of ws[s][i] in a FIXED association (bitwise reproducible): 16 lanes x 16 split groups per block;
+// group g adds slabs g, g + 16, g + 32, ... in that order, the 16 group sums are added pairwise in LDS ((0+1)+(2+3))+...
+// One thread per element walking every slab (the first version) ran 9 - 36 blocks for the small layers: 123 us to add 512
+// slabs of 36 KB, twice the time of the gradient kernel itself.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, float* dw, long n, int splitk) {
-  for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
-    if (i + 4 <= n) {
-      float4v acc = *(const float4v*)(ws + i);
-      for (int s = 1; s < splitk; ++s) {
-        const float4v v = *(const float4v*)(ws + (long)s * n + i);
-        acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
-      }
-      *(float4v*)(dw + i) = acc;
-    } else {
-      for (long j = i; j < n; ++j) {
-        float acc = ws[j];
-        for (int s = 1; s < splitk; ++s) acc += ws[(long)s * n + j];
-        dw[j] = acc;
-      }
+  __shared__ float4v part[16][16];
+  const int tx = threadIdx.x & 15, g = threadIdx.x >> 4;
+  const long i = ((long)blockIdx.x * 16 + tx) * 4;
+  float4v acc = {0.f, 0.f, 0.f, 0.f};
+  if (i + 4 <= n) {
+    for (int s = g; s < splitk; s += 16) {
+      const float4v v = *(const float4v*)(ws + (long)s * n + i);
+      acc[0] += v[0]; acc[1] += v[1]; acc[2] += v[2]; acc[3] += v[3];
     }
+  } else if (i < n) {
+    for (int s = g; s < splitk; s += 16)
+      for (int j = 0; j < 4 && i + j < n; ++j) acc[j] += ws[(long)s * n + i + j];
+  }
+  part[g][tx] = acc;
+  __syncthreads();
+#pragma unroll
+  for (int w = 8; w >= 1; w >>= 1) {
+    if (g < w) {
+      const float4v o = part[g + w][tx];
+      float4v m = part[g][tx];
+      m[0] += o[0]; m[1] += o[1]; m[2] += o[2]; m[3] += o[3];
+      part[g][tx] = m;
+    }
+    __syncthreads();
+  }
+  if (g == 0 && i < n) {
+    const float4v r = part[0][tx];
+    if (i + 4 <= n) *(float4v*)(dw + i) = r;
+    else for (int j = 0; j < 4 && i + j < n; ++j) dw[i + j] = r[j];
   }
 }
 
@@ -224,13 +241,28 @@ size_t conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int 
   int sk = 1, sps = 1;
   const int N = ksize * ksize * Cin;
   wgrad_plan(B * Ho * Wo, Cout, N, &sk, &sps);
-  return sk > 1 ? (size_t)sk * Cout * N * sizeof(float) : 0;
+  size_t need = sk > 1 ? (size_t)sk * Cout * N * sizeof(float) : 0;
+  if (ksize == 3 && conv_wgrad3_ok(B, Ho, Wo, Cin, Cout, 3, 1, 1, 8, 8)) {   // (stride unknown here: cover the stride-1 patch kernel too)
+    const size_t n3 = conv_wgrad3_workspace_bytes(B, Ho, Wo, Cin, Cout);
+    if (n3 > need) need = n3;
+  }
+  return need;
 }
 
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
                       int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
                       const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s) {
   if (ksize < 1 || ksize > 3 || Cin % 8 || Cout % 8 || lddz % 8 || ldx % 8) return -1;
+  if (conv_wgrad3_ok(B, Hi, Wi, Cin, Cout, ksize, stride, pad, lddz, ldx) && Ho == Hi && Wo == Wi) {
+    int sk = 1;
+    const int rc = launch_conv_wgrad3(dz, dz_bstride, lddz, x, x_bstride, ldx, B, Hi, Wi, Cin, Cout, dw, zero, ws, ws_bytes, &sk, s);
+    if (rc != 0) return rc;
+    if (sk > 1) {
+      const long n = (long)Cout * 9 * Cin;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, sk);
+    }
+    return (int)hipGetLastError();
+  }
   WgradArgs a{};
   a.dz = dz; a.dz_bstride = dz_bstride; a.lddz = lddz; a.x = x; a.x_bstride = x_bstride; a.ldx = ldx;
   a.Hi = Hi; a.Wi = Wi; a.Cin = Cin; a.Ho = Ho; a.Wo = Wo; a.Cout = Cout;
@@ -254,9 +286,7 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
   }
   if (a.splitk > 1) {
     const long n = (long)Cout * a.N;
-    long blocks = (n + 1023) / 1024;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)blocks), dim3(256), 0, s, ws, dw, n, a.splitk);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, a.splitk);
   }
   return (int)hipGetLastError();
 }

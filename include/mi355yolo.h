@@ -139,7 +139,7 @@ int m355_conv2d_dgrad(const void* d_dy_f16_nhwc, int B, int H, int W, int cin, c
                       int stride, void* d_dx_f16_nhwc, void* stream);
 /* Weight gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2) (SURVEY A13 backward): X fp16 NHWC (B,H,W,cin),
  * dY fp16 NHWC (B,Ho,Wo,cout) -> dW fp32 DEVICE buffer in KRSC order (cout, k, k, cin) = the packed forward
- * weight order.  Deterministic: split-K partial slabs in a workspace the call allocates, added in split order. [sync] */
+ * weight order.  Deterministic: split-K partial slabs in a workspace the call allocates, added in a fixed order. [sync] */
 int m355_conv2d_wgrad(const void* d_x_f16_nhwc, const void* d_dy_f16_nhwc, int B, int H, int W, int cin, int cout,
                       int k, int stride, float* d_dw_krsc, void* stream);
 /* Train-mode BatchNorm2d (batch statistics, biased variance, eps) + optional SiLU on fp16 NHWC (B,H,W,C)
@@ -200,7 +200,7 @@ typedef struct {
   float* ws; int64_t ws_bytes;                        /* >= m355_wgrad_workspace_bytes(...): split-K partial slabs */
 } m355_wgrad_args;
 /* Deterministic (no float atomics): every K split stores its partial tile to its slab of `ws`, a second kernel adds the
- * slabs in split order.  M355_ERR_INVALID when ws is missing / too small for the shape. */
+ * slabs in a fixed order.  M355_ERR_INVALID when ws is missing / too small for the shape. */
 size_t m355_wgrad_workspace_bytes(int32_t batch, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize);
 int m355_wgrad_launch(const m355_wgrad_args* a, void* stream);
 

@@ -103,7 +103,14 @@ WGRAD_CASES = [
     (2, 32, 32, 64, 128, 3, 2),
     (2, 16, 16, 256, 128, 1, 1),
     (2, 16, 16, 96, 48, 1, 1),        # ragged channel tiles on both sides
-    (8, 40, 40, 128, 224, 3, 1),      # many split-K blocks
+    (8, 40, 40, 128, 224, 3, 1),      # many split-K blocks; patch kernel, 64 x 64 channel tiles, ragged tile columns (40 = 2.5 x 16)
+    # 3x3 / s1 maps at least two tile columns wide take the patch kernel (conv_wgrad3.hip): every wave layout
+    (2, 16, 32, 64, 64, 3, 1),        # 2 x 2 channel blocks, one per wave
+    (2, 24, 40, 32, 32, 3, 1),        # 1 x 1: the four waves split the tile rows
+    (1, 16, 32, 128, 32, 3, 1),       # 1 x 2
+    (1, 19, 35, 32, 64, 3, 1),        # 2 x 1, ragged rows and columns
+    (2, 16, 48, 48, 96, 3, 1),        # m-scale widths: half-empty channel tiles on both sides
+    (3, 8, 32, 16, 24, 3, 1),         # n-scale widths
 ]
 
 

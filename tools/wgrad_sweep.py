@@ -29,7 +29,7 @@ if len(sys.argv) > 2 and sys.argv[1] == "--parse":
         per_call = []
         for rep in range(3):
             t = 0.0
-            assert "conv_wgrad_kernel" in rows[i]["Kernel_Name"], rows[i]["Kernel_Name"]
+            assert "conv_wgrad" in rows[i]["Kernel_Name"], rows[i]["Kernel_Name"]
             t += (int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3; i += 1
             if i < len(rows) and "wgrad_reduce" in rows[i]["Kernel_Name"]:
                 t += (int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3; i += 1
