@@ -14,7 +14,10 @@ namespace {
 
 constexpr int BN_THREADS = 256;
 
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+// v_exp + v_rcp (1 ulp), like the inference epilogues' m355_silu: the IEEE division of 1 / (1 + __expf(-v)) is ~10 VALU
+// instructions per element and made the apply / reduce passes VALU-bound (92 us for 105 M elements = their HBM time)
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
+constexpr int BN_ROWS = 512;   // most partial rows (= blocks) of a reduction launch
 
 constexpr int WS_HEAD = 4;   // floats in front of the partial rows (kept 16-byte aligned)
 
@@ -32,28 +35,35 @@ __device__ __forceinline__ void store_block_partials(const float* red, int C, in
   }
 }
 
-// out[t] = sum over rows b = 0 .. rows-1 of part[b][t], FIXED association: wave w adds rows w, w+4, ... in order into one
-// accumulator (loads issued eight ahead), then the four wave sums are added in wave order.  One block per 64 columns.
-__global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(const float* ws, int n2, int rows, float* out) {
-  __shared__ float wsum[4][64];
+// out[t] = sum over rows b = 0 .. rows-1 of part[b][t], FIXED association: wave w of 16 adds rows w, w+16, ... in order into
+// one accumulator (eight loads in flight), then the sixteen wave sums are added pairwise ((0+1)+(2+3))+...  One block per
+// 64 columns.  (Four waves per block walked 128 rows each: 7 us of pure latency, 132 times per training step.)
+constexpr int FIN_WAVES = 16;
+__global__ __launch_bounds__(FIN_WAVES * 64) void bn_finalize_kernel(const float* ws, int n2, int rows, float* out) {
+  __shared__ float wsum[FIN_WAVES][64];
   const float* const part = ws + WS_HEAD;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   float acc = 0.f;
   if (col < n2) {
     int b = w;
-    for (; b + 28 < rows; b += 32) {
+    for (; b + 7 * FIN_WAVES < rows; b += 8 * FIN_WAVES) {
       float v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = part[(long)(b + 4 * u) * n2 + col];
+      for (int u = 0; u < 8; ++u) v[u] = part[(long)(b + FIN_WAVES * u) * n2 + col];
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += v[u];
     }
-    for (; b < rows; b += 4) acc += part[(long)b * n2 + col];
+    for (; b < rows; b += FIN_WAVES) acc += part[(long)b * n2 + col];
   }
   wsum[w][lane] = acc;
   __syncthreads();
-  if (w == 0 && col < n2) out[col] = ((wsum[0][lane] + wsum[1][lane]) + wsum[2][lane]) + wsum[3][lane];
+#pragma unroll
+  for (int h = FIN_WAVES / 2; h >= 1; h >>= 1) {
+    if (w < h) wsum[w][lane] += wsum[w + h][lane];
+    __syncthreads();
+  }
+  if (w == 0 && col < n2) out[col] = wsum[0][lane];
 }
 
 // partial rows of sum_px z (columns 0:C) and sum_px z^2 (C:2C)   (ws: WS_HEAD + gridDim.x * 2C floats)
@@ -371,34 +381,36 @@ int grid_for(long work_items) {
 }
 
 // blocks for the pixel-walking apply kernels: 4 pixels per thread per trip, at most 16 blocks per CU
-// reduction kernels end with 2 C same-address atomics per block: few, fat blocks (one per CU; four loads in flight per thread)
+// reduction kernels: every block writes one partial row; two blocks per CU (one left HBM at 3.1 - 3.7 TB/s)
 int grid_red(long work_items) {
   const int g = grid_for(work_items);
-  return g > 256 ? 256 : g;
+  return g > BN_ROWS ? BN_ROWS : g;
 }
 
 int grid_px(long npix, int lanes_px) {
-  long b = (npix + (long)lanes_px * 4 - 1) / ((long)lanes_px * 4);
-  if (b > 256 * 16) b = 256 * 16;
+  // at least 16 pixels per thread: a thread's prologue is ~30 dependent-latency loads of per-channel constants, and with 4
+  // pixels each (C = 256: 8 pixel lanes per block) the apply pass ran at 1.8 TB/s
+  long b = (npix + (long)lanes_px * 16 - 1) / ((long)lanes_px * 16);
+  if (b > 256 * 8) b = 256 * 8;
   if (b < 1) b = 1;
   return (int)b;
 }
 
 }  // namespace
 
-size_t bn_workspace_floats(int C) { return (size_t)WS_HEAD + (size_t)256 * 2 * C + 2 * C; }
+size_t bn_workspace_floats(int C) { return (size_t)WS_HEAD + (size_t)BN_ROWS * 2 * C + 2 * C; }
 
-// ws: bn_workspace_floats(C) floats (per-block partial rows, then the 2C batch sums at ws[WS_HEAD + 256 * 2C ...])
+// ws: bn_workspace_floats(C) floats (per-block partial rows, then the 2C batch sums at ws[WS_HEAD + BN_ROWS * 2C ...])
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,
                              float eps, half_t* y, int ldy, const half_t* res, int ldr, float* sums, float* mean_out,
                              float* invstd_out, int act, float* run_mean, float* run_var, float momentum, hipStream_t s) {
   if (C % 8 || ldz % 8 || ldy % 8 || C / 8 > BN_THREADS) return -1;
   const int lanes_px = BN_THREADS / (C / 8);
   float* const ws = sums;
-  float* const tot = ws + WS_HEAD + (size_t)256 * 2 * C;
+  float* const tot = ws + WS_HEAD + (size_t)BN_ROWS * 2 * C;
   const int gr = grid_red(npix * BN_THREADS / lanes_px / 4);
   hipLaunchKernelGGL(bn_stats_kernel, dim3(gr), dim3(BN_THREADS), BN_THREADS * 16 * sizeof(float), s, z, npix, ldz, C, ws);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((2 * C + 63) / 64), dim3(BN_THREADS), 0, s, ws, 2 * C, gr, tot);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((2 * C + 63) / 64), dim3(FIN_WAVES * 64), 0, s, ws, 2 * C, gr, tot);
   hipLaunchKernelGGL(bn_silu_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, npix, ldz, C, tot,
                      gamma, beta, eps, y, ldy, res, ldr, mean_out, invstd_out, act, run_mean, run_var, momentum);
   return (int)hipGetLastError();
@@ -413,7 +425,7 @@ int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int l
   const int gr = grid_red(npix * BN_THREADS / lanes_px / 4);
   hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(gr), dim3(BN_THREADS), BN_THREADS * 16 * sizeof(float), s, z, dy, npix, ldz,
                      lddy, C, mean, invstd, gamma, beta, act, ws);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((2 * C + 63) / 64), dim3(BN_THREADS), 0, s, ws, 2 * C, gr, rsum);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((2 * C + 63) / 64), dim3(FIN_WAVES * 64), 0, s, ws, 2 * C, gr, rsum);
   hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
                      lddy, C, mean, invstd, gamma, beta, rsum, dz, lddz, act);
   return (int)hipGetLastError();
