@@ -60,6 +60,8 @@ struct Op {
   int tile = -1;
   int decode = 0;         // head output conv that also decodes its rows into the prediction tensor (no OP_DECODE launch)
   int s2c32 = 0;          // conv 3x3/s2 (32 -> 64) + 1x1 (64 -> 64) on the dedicated patch kernel (conv3x3_s2c32.hip)
+  int stemfuse = -1;      // >= 0: index of the stem op this launch also computes (conv_stem_s2c32.hip); that op is then skipped
+  bool fused_away = false;
   // stream lanes (plan_lanes): lane 0 is the caller's stream, lanes >= 1 are engine-owned side streams
   int lane = 0;
   std::vector<int> wait_ops;   // ops on OTHER lanes whose completion event this op's stream waits for before the launch
@@ -124,6 +126,7 @@ struct m355_engine {
   bool profiling = false;
   std::vector<hipEvent_t> ev_pool;   // 2 events per op per recorded forward
   size_t ev_used = 0;
+  std::vector<int> ev_op;    // op index of every recorded event pair (ops fused into a neighbour record none)
   std::vector<double> op_ms;         // accumulated per-op milliseconds
   std::vector<long> op_cnt;
 
@@ -920,6 +923,25 @@ void annotate_ops(m355_engine* e) {
         break;
     }
   }
+  // stem + model.1 (+ cv1) in one launch when the patch kernel takes model.1 and the stem feeds nothing else (conv_stem_s2c32.hip)
+  for (size_t i = 0; i + 1 < e->ops.size(); ++i) {
+    Op& st = e->ops[i];
+    Op& nx = e->ops[i + 1];
+    if (st.kind != OP_STEM || !nx.s2c32 || nx.in.t != st.out.t || st.lane != nx.lane || st.record || getenv("M355_NO_STEMFUSE")) continue;
+    bool other = false;
+    for (size_t j = i + 2; j < e->ops.size(); ++j)
+      if (e->ops[j].in.t == st.out.t || e->ops[j].res.t == st.out.t || e->ops[j].in2.t == st.out.t) other = true;
+    if (other || e->phys[st.conv].cout != 32 || (st.Wi * 3) % 16) continue;
+    nx.stemfuse = (int)i;
+    st.fused_away = true;
+    const Tensor& to = e->tensors[nx.out.t];
+    snprintf(nx.kernel, sizeof(nx.kernel), "stem+conv3x3_s2c32<8x16px>+1x1");
+    snprintf(nx.layer, sizeof(nx.layer), "model.0+model.1+model.2.cv1");
+    nx.flops += st.flops;
+    nx.bytes = (double)st.Hi * st.Wi * 3 + (double)to.H * to.W * e->phys[nx.conv].cout2 * 2;
+    nx.wbytes += st.wbytes;
+    st.flops = st.bytes = st.wbytes = 0;
+  }
 }
 
 // Pack fp32 (cout,cin,k,k) -> fp16 rows [row0+co][ (kh*k+kw)*cin + ci ] of a [cout_pad][Kpad] matrix.
@@ -1136,6 +1158,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
   auto run_range = [&](size_t lo, size_t hi, const int b0, const int Bq) -> int {
   for (size_t oi = lo; oi < hi; ++oi) {
     const Op& op = e->ops[oi];
+    if (op.fused_away) continue;
     int rc = 0;
     hipStream_t s = (lanes && op.lane > 0) ? e->side[op.lane - 1] : s_main;
     if (lanes)
@@ -1236,6 +1259,22 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2;
         }
         a.tileq = knobs().static_tiles ? nullptr : e->tileq + 4 * oi;
+        if (op.stemfuse >= 0) {
+          const Op& so = e->ops[op.stemfuse];
+          const PhysConv& sp = e->phys[so.conv];
+          const Tensor& sto = e->tensors[so.out.t];
+          StemArgs sa{};
+          sa.x = (const uint8_t*)d_in + (long)b0 * so.Hi * so.Wi * 3; sa.B = Bq; sa.H = so.Hi; sa.W = so.Wi;
+          sa.w16 = (const half_t*)sp.stem_w; sa.bias = sp.bias;
+          sa.y_bstride = (long)sto.H * sto.W * sto.C; sa.ldy = sto.C; sa.Cout = sp.cout;
+          sa.y = sto.p + so.out.off + b0 * sa.y_bstride;
+          if (stem_s2c32_ok(a, sa)) {
+            rc = launch_stem_s2c32(a, sa, s);
+            break;
+          }
+          rc = launch_stem(sa, s);            // not eligible after all (shape): the two launches
+          if (rc != 0) break;
+        }
         rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
              : (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
              : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
@@ -1271,6 +1310,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
     if (e->profiling) {
       HIP_TRY(e, hipEventRecord(e->ev_pool[e->ev_used + 1], s));
       e->ev_used += 2;
+      e->ev_op.push_back((int)oi);
     }
     if (rc != 0) return e->fail(M355_ERR_HIP, "kernel launch failed (op kind " + std::to_string((int)op.kind) +
                                                   ", code " + std::to_string(rc) + ")");
@@ -1322,7 +1362,7 @@ int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts) {
   const size_t n = e->ops.size();
   if (e->op_ms.size() != n) { e->op_ms.assign(n, 0.0); e->op_cnt.assign(n, 0); }
   for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
-    const size_t oi = (i / 2) % n;
+    const size_t oi = (size_t)e->ev_op[i / 2];
     HIP_TRY(e, hipEventSynchronize(e->ev_pool[i + 1]));
     float ms = 0.f;
     HIP_TRY(e, hipEventElapsedTime(&ms, e->ev_pool[i], e->ev_pool[i + 1]));
@@ -1330,6 +1370,7 @@ int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts) {
     e->op_cnt[oi] += 1;
   }
   e->ev_used = 0;
+  e->ev_op.clear();
   for (size_t i = 0; i < n; ++i) { ms_sum[i] = e->op_ms[i]; counts[i] = e->op_cnt[i]; }
   e->op_ms.assign(n, 0.0);
   e->op_cnt.assign(n, 0);

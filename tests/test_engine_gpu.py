@@ -428,3 +428,36 @@ def test_decode_in_the_head_epilogue_is_bit_identical(cuda_device):
     assert torch.equal(outs["fused"][0], outs["separate"][0]) and torch.equal(outs["fused_keep_raw"][0], outs["separate"][0])
     assert torch.equal(outs["fused"][1], outs["separate"][1])
     assert torch.equal(outs["fused_keep_raw"][2], outs["separate"][2])
+
+
+def test_stem_fused_into_the_patch_kernel_matches_the_two_launches(cuda_device):
+    """model.0 + model.1 + model.2.cv1 in one launch (conv_stem_s2c32.hip: the patch of the stem output is computed from the
+    uint8 window in LDS and never stored) against stem launch + patch kernel.  Same MFMA shape and tap order for the stem, so
+    the only differences are the last-bit rounding of its epilogue; batch 5 covers every border class of the tiles (first /
+    last tile rows and columns: the zero padding of the stem AND of model.1)."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(5, seed=34)).to(cuda_device)
+    outs = []
+    for off in (False, True):
+        if off:
+            os.environ["M355_NO_STEMFUSE"] = "1"
+        try:
+            eng = SegEngine("s", 1, (640, 640), max_batch=5)
+        finally:
+            os.environ.pop("M355_NO_STEMFUSE", None)
+        kinds = [o["kernel"] for o in eng.op_infos()]
+        assert any(k.startswith("stem+") for k in kinds) == (not off), kinds
+        eng.load_state_dict(sd)
+        p, q = eng.forward(imgs)
+        raw = eng.raw_head(5)
+        torch.cuda.synchronize()
+        outs.append((p.clone(), q.clone(), raw.clone()))
+        eng.close()
+    rel = lambda a, b: float((a.float() - b.float()).norm() / b.float().norm())  # noqa: E731
+    e_raw, e_pr = rel(outs[0][2], outs[1][2]), rel(outs[0][1], outs[1][1])
+    print(f"stem fused vs two launches: raw head rel-L2 {e_raw:.2e}, prototypes rel-L2 {e_pr:.2e}")
+    assert torch.isfinite(outs[0][2]).all()
+    assert e_raw <= 2e-3 and e_pr <= 2e-3

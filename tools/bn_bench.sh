@@ -16,5 +16,5 @@ for i, sh in enumerate(shapes):
         d = (int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3
         best[n] = min(best.get(n, 1e9), d)
     mult = {'stats': 1, 'silu_apply': 2, 'silu_bwd_reduce': 2, 'silu_bwd_apply': 3, 'finalize': 0}
-    print(sh, " | ".join(f"{n}: {d:.1f} us" + (f" {mult[n]*mb/d:.0f} GB/s" if mult.get(n) else "") for n, d in best.items()))
+    print(sh, " | ".join(f"{n}: {d:.1f} us" + (f" {mult[n]*mb/d*1e3:.0f} GB/s" if mult.get(n) else "") for n, d in best.items()))
 PY
