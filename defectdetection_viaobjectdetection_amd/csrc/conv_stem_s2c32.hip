@@ -196,7 +196,8 @@ __global__ __launch_bounds__(512, 2) void stem_s2c32_cv1_kernel(const ConvArgs a
         const float4v u = *(const float4v*)(smem + BIAS_OFF + 512 + (8 * g + 4 * mt) * 4);
         b0[mt][0] = u[0]; b0[mt][1] = u[1]; b0[mt][2] = u[2]; b0[mt][3] = u[3];
       }
-      for (int blk = wave; blk < NBLK; blk += NWAVES) {
+      // one block of 16 patch pixels: gather (8 taps per lane), two MFMAs, SiLU, one 16-byte write into the patch image
+      auto gather = [&](int blk, int& dst, unsigned& keep) __attribute__((always_inline)) -> half8 {
         const int p = blk * 16 + l15;
         const bool pv = p < NPX;
         const int pp = pv ? p : NPX - 1;
@@ -205,27 +206,40 @@ __global__ __launch_bounds__(512, 2) void stem_s2c32_cv1_kernel(const ConvArgs a
         half8 xf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) xf[j] = (half_t)(float)(unsigned)base[toff[j]];
-        const half8 wf0 = *(const half8*)(smem + W0_OFF + l15 * 64 + g * 16);
-        const half8 wf1 = *(const half8*)(smem + W0_OFF + (16 + l15) * 64 + g * 16);
-        float4v acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0, xf, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, xf, acc1, 0, 0, 0);
+        // patch pixel (pr, pc) = stem pixel (2 y0 - 1 + pr, 2 x0 - 1 + pc): outside the map only on the first row / column ->
+        // zeros (the padding of model.1), branch-free: the 16 bytes are ANDed with a mask
+        keep = ((y0 == 0 && pr == 0) || (x0 == 0 && pc == 0)) ? 0u : 0xffffffffu;
+        const int jj = pc >> 1;
+        const int R = pv ? (pr * 2 + (pc & 1)) * PJ + jj : PJ - 1;       // pixels past the patch: a pad row nobody reads (plane 0, j = 19)
+        dst = R * 64 + ((g ^ ((jj >> 2) & 3)) << 4);
+        return xf;
+      };
+      auto finish = [&](const float4v& acc0, const float4v& acc1, int dst, unsigned keep) __attribute__((always_inline)) {
         half8 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           o[j] = m355_to_half(m355_silu(acc0[j] * inv255 + b0[0][j]));
           o[4 + j] = m355_to_half(m355_silu(acc1[j] * inv255 + b0[1][j]));
         }
-        // patch pixel (pr, pc) = stem pixel (2 y0 - 1 + pr, 2 x0 - 1 + pc): outside the map only on the first row / column ->
-        // zeros (the padding of model.1); branch-free: the 16 bytes are ANDed with a mask
-        const unsigned keep = ((y0 == 0 && pr == 0) || (x0 == 0 && pc == 0)) ? 0u : 0xffffffffu;
         uint4v ov = *(const uint4v*)&o;
         ov[0] &= keep; ov[1] &= keep; ov[2] &= keep; ov[3] &= keep;
-        if (pv) {
-          const int jj = pc >> 1;
-          const int R = (pr * 2 + (pc & 1)) * PJ + jj;
-          *(uint4v*)(smem + R * 64 + ((g ^ ((jj >> 2) & 3)) << 4)) = ov;
-        }
+        *(uint4v*)(smem + dst) = ov;
+      };
+      const half8 wf0 = *(const half8*)(smem + W0_OFF + l15 * 64 + g * 16);
+      const half8 wf1 = *(const half8*)(smem + W0_OFF + (16 + l15) * 64 + g * 16);
+      const float4v z4 = {0.f, 0.f, 0.f, 0.f};
+      for (int blk = wave; blk < NBLK; blk += 2 * NWAVES) {     // two blocks per trip: their read -> convert -> MFMA -> SiLU chains interleave
+        const bool two = blk + NWAVES < NBLK;                    // (uniform per wave)
+        int d0, d1;
+        unsigned k0, k1;
+        const half8 x0f = gather(blk, d0, k0);
+        const half8 x1f = gather(two ? blk + NWAVES : blk, d1, k1);
+        const float4v a00 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0, x0f, z4, 0, 0, 0);
+        const float4v a01 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, x0f, z4, 0, 0, 0);
+        const float4v a10 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf0, x1f, z4, 0, 0, 0);
+        const float4v a11 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf1, x1f, z4, 0, 0, 0);
+        finish(a00, a01, d0, k0);
+        if (two) finish(a10, a11, d1, k1);
       }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
