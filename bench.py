@@ -227,6 +227,8 @@ def main():
             infos = eng.op_infos()
             by_kernel = {}
             for info, ms, c in zip(infos, ms_sum, cnt):
+                if c == 0:
+                    continue            # an op computed inside a neighbour's launch (the stem inside the model.1 patch kernel)
                 k = by_kernel.setdefault(info["kernel"], dict(ms=0.0, launches=0, flops=0.0, bytes=0.0))
                 k["ms"] += ms
                 k["launches"] += c
