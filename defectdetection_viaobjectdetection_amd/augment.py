@@ -134,6 +134,8 @@ class Augmenter:
         imgs = self.render(plans)
         bidx, cls, boxes = [], [], []
         masks = np.zeros((len(plans), H // 4, W // 4), np.uint8)
+        if any(len(p["inst"]) > 255 for p in plans):                 # (a mosaic of four crowded images)
+            masks = masks.astype(np.int32)
         for b, p in enumerate(plans):
             polys = [q for _, q in p["inst"]]
             if not polys:

@@ -230,7 +230,8 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
       if (touch_flag[d]) continue;
       uint8_t* mp = masks + (((long)b * max_det + d) * in_h + Y) * in_w + X0;
       if (X0 + 16 <= in_w) {
-        __builtin_nontemporal_store(uint4v{0u, 0u, 0u, 0u}, (uint4v*)mp);
+        if (dbg & 4) *(uint4v*)mp = uint4v{0u, 0u, 0u, 0u};
+        else __builtin_nontemporal_store(uint4v{0u, 0u, 0u, 0u}, (uint4v*)mp);
       } else {
         for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = 0;
       }
@@ -315,7 +316,8 @@ __global__ __launch_bounds__(256) void proto_masks_kernel(const float* dets, con
         if (dbg & 2) continue;
         if (X0 + 16 <= in_w) {
           typedef unsigned uint4v __attribute__((ext_vector_type(4)));
-          __builtin_nontemporal_store(*(const uint4v*)o, (uint4v*)mp);   // written once, never read by the GPU again
+          if (dbg & 4) *(uint4v*)mp = *(const uint4v*)o;
+          else __builtin_nontemporal_store(*(const uint4v*)o, (uint4v*)mp);   // written once, never read by the GPU again
         } else {
           for (int j = 0; j < 16 && X0 + j < in_w; ++j) mp[j] = o[j];
         }

@@ -95,8 +95,9 @@ def rasterize_polygon(poly_px: np.ndarray, h: int, w: int) -> np.ndarray:
 
 
 def overlap_mask(polys_px: Sequence[np.ndarray], imgsz: Tuple[int, int], ratio: int = 4) -> Tuple[np.ndarray, np.ndarray]:
-    """A.4 "GT masks": one (H/ratio, W/ratio) uint8 map whose value is (instance index + 1) with instances ordered by
-    mask area descending, later (smaller) instances overwriting earlier ones.  Returns (map, order)."""
+    """A.4 "GT masks": one (H/ratio, W/ratio) map whose value is (instance index + 1) with instances ordered by mask area
+    descending, later (smaller) instances overwriting earlier ones.  uint8, or int32 when an image holds more than 255
+    instances (upstream's rule; a uint8 map would wrap around).  Returns (map, order)."""
     H, W = imgsz
     mh, mw = H // ratio, W // ratio
     small = []
@@ -104,7 +105,7 @@ def overlap_mask(polys_px: Sequence[np.ndarray], imgsz: Tuple[int, int], ratio: 
         full = rasterize_polygon(p, H, W).astype(np.float32)
         small.append(full.reshape(mh, ratio, mw, ratio).mean((1, 3)) >= 0.5)
     order = np.argsort([-int(m.sum()) for m in small], kind="stable") if small else np.zeros(0, np.int64)
-    out = np.zeros((mh, mw), np.uint8)
+    out = np.zeros((mh, mw), np.uint8 if len(small) <= 255 else np.int32)
     for rank, j in enumerate(order):
         out[small[j]] = rank + 1
     return out, order
@@ -145,6 +146,8 @@ class SegDataset:
         imgs = self.images[list(indices)]
         bidx, cls, boxes = [], [], []
         masks = np.zeros((len(indices), H // 4, W // 4), np.uint8)
+        if any(len(self.labels[i]) > 255 for i in indices):
+            masks = masks.astype(np.int32)
         for b, i in enumerate(indices):
             polys = [p for _, p in self.labels[i]]
             if flip is not None and flip[b]:

@@ -85,3 +85,18 @@ def test_annotations_converter_handles_reversed_x(tmp_path):
             assert inst, "every excerpt image has at least one usable box"
             for _, p in inst:
                 assert p[:, 0].max() > p[:, 0].min() and p[:, 1].max() > p[:, 1].min()   # x_min > x_max input is repaired
+
+
+def test_overlap_mask_switches_to_int32_beyond_255_instances():
+    """A.4: the overlap map stores instance index + 1; with more than 255 instances uint8 would wrap around (upstream
+    switches to int32 there as well)."""
+    from defectdetection_viaobjectdetection_amd.dataset import overlap_mask
+    polys = []
+    for i in range(300):                                    # 300 squares of 8 x 8 px on a 20 x 15 grid, 160 x 256 map at ratio 4... of a 640 x 1024 image
+        y, x = (i // 20) * 40, (i % 20) * 48
+        polys.append(np.array([[x, y], [x + 32, y], [x + 32, y + 32], [x, y + 32]], np.float32))
+    m, order = overlap_mask(polys, (640, 1024))
+    assert m.dtype == np.int32 and len(order) == 300
+    assert sorted(np.unique(m).tolist()) == list(range(0, 301))
+    m2, _ = overlap_mask(polys[:200], (640, 1024))
+    assert m2.dtype == np.uint8 and m2.max() == 200
