@@ -173,9 +173,9 @@ def main():
     sampled = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # every n-th step; a run shorter than n samples its middle step only (sampled steps give up all overlap)
-        on = profile and (i % args.profile_every == args.profile_every // 2 or
-                          (args.steps < args.profile_every and i == args.steps // 2))
+        # every n-th step counted back from the LAST one (a run shorter than n samples its last step only).  A sampled step
+        # gives up all overlap: the pipeline drains before it and refills after it -- the last step has no refill to pay.
+        on = profile and (args.steps - 1 - i) % args.profile_every == 0
         cur = engs[step_no[0] % n_eng]
         if on:
             cur.set_profiling(True)
