@@ -114,6 +114,7 @@ SIGNATURES = {
     "m355_msda_module_forward": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int32, _P, _P, _P, _P,
                                            C.c_int32, C.c_int32, C.c_float, _P, _P]),
     "m355_dfine_decode": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32, C.c_float, C.c_int32, _P]),
+    "m355_repack_launch": (C.c_int, [_P, _P, C.c_int32, _P]),
     "m355_sppf_pool_bwd_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, _P, C.c_int64,
                                              C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P]),
     "m355_sppf_pool_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

@@ -165,6 +165,7 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
                       const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s);
 // floats of workspace the train-mode batch-norm launches need for C channels (per-block partial sums + ticket)
 size_t bn_workspace_floats(int C);
+int launch_repack(const void* d_jobs /* m355_repack_job[] (include/mi355yolo.h) */, const int* d_block_job, int nblocks, hipStream_t s);
 
 // train-mode BatchNorm + SiLU (train_kernels.hip)
 int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const float* gamma, const float* beta,

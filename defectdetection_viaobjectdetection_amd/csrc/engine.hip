@@ -1793,6 +1793,11 @@ int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "sppf launch failed: " + std::to_string(rc));
 }
 
+int m355_repack_launch(const m355_repack_job* d_jobs, const int32_t* d_block_job, int32_t nblocks, void* stream) {
+  const int rc = launch_repack(d_jobs, d_block_job, nblocks, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "repack launch failed: " + std::to_string(rc));
+}
+
 int m355_sppf_pool_bwd_launch(const void* a, int64_t a_bstride, int32_t lda, const void* y, int64_t y_bstride, int32_t ldy,
                               const void* gy, int64_t gy_bstride, int32_t ldgy, void* ga, int64_t ga_bstride, int32_t ldga,
                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream) {

@@ -8,6 +8,7 @@
 // ~100 us per launch: one block reading 256 rows is a serial tail; the separate kernel costs what the memset of the
 // atomic version did -- one more stream operation.)
 #include "common.h"
+#include "../../include/mi355yolo.h"
 
 namespace m355 {
 namespace {
@@ -554,6 +555,39 @@ int launch_sppf_pool_bwd(const half_t* a, long a_bs, int lda, const half_t* y, l
   }
   hipLaunchKernelGGL(sppf_pool_bwd_kernel, dim3(B * (C / 8)), dim3(256), lds, s, a, a_bs, lda, y, y_bs, ldy, gy, gy_bs, ldgy, ga,
                      ga_bs, ldga, H, W, C, accumulate);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Re-pack of the fp32 master weights into the fp16 GEMM layouts after an optimizer step (forward [Cout][(kh,kw,ci)], dgrad
+// [Cin][(kh',kw',co)] with flipped taps, ConvTranspose forms): ~150 strided convert-copies per step were ~150 launch-bound
+// torch kernels (1.8 ms of a 37 ms step).  Here every copy is a JOB -- a 4-d iteration space with signed element strides
+// on both sides (a flip is a negative source stride) -- and one launch walks all jobs: block b works on 1024 consecutive
+// elements of job block_job[b] (innermost dimension fastest = contiguous fp16 stores).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void repack_kernel(const ::m355_repack_job* jobs, const int* block_job) {
+  const ::m355_repack_job j = jobs[block_job[blockIdx.x]];
+  const long total = (long)j.n[0] * j.n[1] * j.n[2] * j.n[3];
+  const long base = (long)(blockIdx.x - j.block0) * 1024;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const long e = base + u * 256 + threadIdx.x;
+    if (e >= total) break;
+    long r = e;
+    const int i3 = (int)(r % j.n[3]); r /= j.n[3];
+    const int i2 = (int)(r % j.n[2]); r /= j.n[2];
+    const int i1 = (int)(r % j.n[1]); r /= j.n[1];
+    const int i0 = (int)r;
+    const float v = ((const float*)j.src)[i0 * j.ss[0] + i1 * j.ss[1] + i2 * j.ss[2] + i3 * j.ss[3]];
+    ((half_t*)j.dst)[i0 * j.ds[0] + i1 * j.ds[1] + i2 * j.ds[2] + i3 * j.ds[3]] = (half_t)v;
+  }
+}
+}  // namespace
+
+int launch_repack(const void* d_jobs, const int* d_block_job, int nblocks, hipStream_t s) {
+  if (!d_jobs || !d_block_job || nblocks < 1) return -1;
+  hipLaunchKernelGGL(repack_kernel, dim3(nblocks), dim3(256), 0, s, (const ::m355_repack_job*)d_jobs, d_block_job);
   return (int)hipGetLastError();
 }
 

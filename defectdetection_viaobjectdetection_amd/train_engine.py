@@ -235,24 +235,56 @@ class TrainEngine:
             self.packed[key] = out
         return out[:rows, :K].view(shape)
 
-    def repack(self) -> None:
-        """fp32 master weights -> fp16 GEMM layouts: forward [Cout][(kh,kw,ci)] and dgrad [Cin][(kh',kw',co)].
-        Padded rows / channels (stem 3 -> 8 input channels, nc -> 8 class rows) stay zero from the allocation."""
+    def _repack_pairs(self):
+        """(destination fp16 view, source fp32 view, flipped dims) of every strided convert-copy of a re-pack: forward
+        [Cout][(kh,kw,ci)] and dgrad [Cin][(kh',kw',co)] layouts.  Padded rows / channels (stem 3 -> 8 input channels,
+        nc -> 8 class rows) stay zero from the allocation."""
+        out = []
         for s in self.specs.values():
             if s.transposed:
                 w = self.params[f"{s.name}.weight"]                       # (cin, cout, 2, 2)
-                self._pack_view(s.name + ":fwd", 4 * s.cout, s.cin, (2, 2, s.cout, s.cin)).copy_(w.permute(2, 3, 1, 0))
-                self._pack_view(s.name + ":dgrad", s.cin, 4 * s.cout, (s.cin, 2, 2, s.cout)).copy_(w.permute(0, 2, 3, 1))
+                out.append((self._pack_view(s.name + ":fwd", 4 * s.cout, s.cin, (2, 2, s.cout, s.cin)), w.permute(2, 3, 1, 0), ()))
+                out.append((self._pack_view(s.name + ":dgrad", s.cin, 4 * s.cout, (s.cin, 2, 2, s.cout)), w.permute(0, 2, 3, 1), ()))
                 continue
             w = self.params[f"{s.name}.conv.weight" if s.has_bn else f"{s.name}.weight"]  # (cout, k, k, cin)
             k = s.k
             cin_p = 8 if s.cin == 3 else s.cin                              # stem: input padded to 8 channels
             cout_p = _ceil(s.cout, 8)                                       # class branch (nc) -> rows padded to 8
-            self._pack_view(s.name + ":fwd", cout_p, k * k * cin_p, (cout_p, k, k, cin_p))[:s.cout, :, :, :s.cin].copy_(w)
-            if s.cin != 3:
-                wd = w if s.stride == 2 else w.flip(1, 2)                   # stride 2 = transposed-stride gather, no flip
-                self._pack_view(s.name + ":dgrad", cin_p, k * k * cout_p, (cin_p, k, k, cout_p))[..., :s.cout].copy_(
-                    wd.permute(3, 1, 2, 0))
+            out.append((self._pack_view(s.name + ":fwd", cout_p, k * k * cin_p, (cout_p, k, k, cin_p))[:s.cout, :, :, :s.cin], w, ()))
+            if s.cin != 3:                                                  # stride 2 = transposed-stride gather, no flip
+                out.append((self._pack_view(s.name + ":dgrad", cin_p, k * k * cout_p, (cin_p, k, k, cout_p))[..., :s.cout],
+                            w.permute(3, 1, 2, 0), () if s.stride == 2 else (1, 2)))
+        return out
+
+    def _repack_torch(self) -> None:
+        """The re-pack as one torch convert-copy per layout (the form the job kernel replaced; kept for its test)."""
+        for dst, src, flips in self._repack_pairs():
+            dst.copy_(src.flip(*flips) if flips else src)
+
+    def repack(self) -> None:
+        """fp32 master weights -> fp16 GEMM layouts in ONE launch (m355_repack_launch): the job table is built once, the
+        parameter and layout buffers of an engine never move."""
+        if getattr(self, "_repack_jobs", None) is None:
+            import numpy as np
+            dt = np.dtype([("src", "<u8"), ("dst", "<u8"), ("n", "<i4", 4), ("ss", "<i8", 4), ("ds", "<i8", 4), ("block0", "<i4"), ("pad", "<i4")])
+            jobs, block_job = [], []
+            for dst, src, flips in self._repack_pairs():
+                assert tuple(dst.shape) == tuple(src.shape) and dst.dim() == 4 and dst.dtype == torch.float16 and src.dtype == torch.float32
+                n, ss, ds = list(dst.shape), list(src.stride()), list(dst.stride())
+                sp = src.data_ptr()
+                for d in flips:                                             # a flip = start at the far end, negative stride
+                    sp += (n[d] - 1) * ss[d] * 4
+                    ss[d] = -ss[d]
+                total = n[0] * n[1] * n[2] * n[3]
+                if total == 0:
+                    continue
+                jobs.append((sp, dst.data_ptr(), n, ss, ds, len(block_job), 0))
+                block_job += [len(jobs) - 1] * ((total + 1023) // 1024)
+            arr = np.array(jobs, dtype=dt)
+            self._repack_jobs = torch.from_numpy(arr.view(np.uint8).reshape(-1)).to(self.dev)
+            self._repack_blocks = torch.tensor(block_job, dtype=torch.int32, device=self.dev)
+        check(lib.m355_repack_launch(C.c_void_p(self._repack_jobs.data_ptr()), C.c_void_p(self._repack_blocks.data_ptr()),
+                                     int(self._repack_blocks.numel()), self._stream()))
 
     # ------------------------------------------------------------------ kernel plumbing
     def _stream(self):

@@ -215,6 +215,20 @@ int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_
                              void* dz, int32_t lddz, float* dbeta_dgamma, float* ws, void* stream);
 int m355_sppf_pool_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                           int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* Re-pack of fp32 master weights into fp16 GEMM layouts, every strided convert-copy of a training step in one launch.
+ * A job copies a 4-d iteration space n[0..3] (n[3] fastest) from fp32 `src` to fp16 `dst` with signed ELEMENT strides on both
+ * sides; block0 = index of the job's first block; block b of the launch handles elements [(b - block0) * 1024, +1024) of job
+ * block_job[b].  Jobs and block_job live in DEVICE memory (built once: the pointers of a training engine never move). */
+typedef struct m355_repack_job {
+  const void* src;
+  void* dst;
+  int32_t n[4];
+  int64_t ss[4];
+  int64_t ds[4];
+  int32_t block0;
+  int32_t pad_;
+} m355_repack_job;
+int m355_repack_launch(const m355_repack_job* d_jobs, const int32_t* d_block_job, int32_t nblocks, void* stream);
 /* Backward of the SPPF pooling chain (autograd of three F.max_pool2d(5, 1, 2) upstream): a = the pooled input slice, y = the
  * forward concat slice [y1 | y2 | y3] (3C channels), gy = its gradient, ga = d(loss)/da stored (accumulate = 0) or added to
  * what ga holds (fp16).  Gather formulation, no atomics: bitwise reproducible.  H * W * 96 bytes of LDS (<= 160 KB). */

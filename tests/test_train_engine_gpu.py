@@ -123,3 +123,23 @@ def test_forward_backward_is_bitwise_reproducible(cuda_device):
     for o in outs[1:]:
         assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
         assert torch.equal(o[2], outs[0][2]), int((o[2] != outs[0][2]).sum())
+
+
+def test_repack_job_kernel_equals_the_torch_copies(cuda_device):
+    """One launch over a job table (m355_repack_launch) writes exactly what the ~150 strided torch convert-copies wrote:
+    forward and dgrad (flipped-tap, transposed) fp16 layouts of every conv, ConvTranspose forms included."""
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
+    eng = TrainEngine("n", 3, (64, 96), 2)
+    eng.load_state_dict(synthetic_state_dict("n", 3, seed=11))
+    eng.flat_params[:eng.n_train].add_(torch.randn(eng.n_train, device=cuda_device) * 0.01)      # new weights since the load-time re-pack
+    eng.repack()
+    torch.cuda.synchronize()
+    got = {k: v.clone() for k, v in eng.packed.items()}
+    for v in eng.packed.values():
+        v.zero_()
+    eng._repack_torch()
+    torch.cuda.synchronize()
+    assert len(got) > 100
+    for k, v in eng.packed.items():
+        assert torch.equal(got[k], v), k
