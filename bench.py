@@ -290,7 +290,7 @@ def train_step_bench(world, dist, steps=4, warm=2):
     import numpy as np
     import torch
     from defectdetection_viaobjectdetection_amd._capi import check, lib
-    from defectdetection_viaobjectdetection_amd.loss import segmentation_loss
+    from defectdetection_viaobjectdetection_amd.loss import GraphedSegLoss
     from defectdetection_viaobjectdetection_amd.sharding import GradBucketReducer
     from defectdetection_viaobjectdetection_amd.spec import init_state_dict
     from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
@@ -308,6 +308,7 @@ def train_step_bench(world, dist, steps=4, warm=2):
     masks[:, 60:70, 60:70] = 2
     batch = {"batch_idx": torch.arange(B).repeat_interleave(2).float().to(dev), "cls": torch.zeros(n, device=dev), "bboxes": boxes,
              "masks": masks}
+    criterion = GraphedSegLoss(1, (S, S))
     m1 = torch.zeros(eng.n_train, device=dev)
     m2 = torch.zeros(eng.n_train, device=dev)
     ema = eng.flat_params.clone()
@@ -322,14 +323,12 @@ def train_step_bench(world, dist, steps=4, warm=2):
         t0 = tick()
         raw, protos = eng.forward(imgs)
         t1 = tick()
-        r = raw.detach().clone().requires_grad_(True)
-        p = protos.detach().float().requires_grad_(True)
-        loss, _ = segmentation_loss(r, p, batch, 1, (S, S))
-        (loss * 128.0).backward()
+        items, d_raw, d_protos = criterion(raw, protos, batch, 128.0)     # loss + backward of the loss: one hipGraph replay
+        loss = items.sum() * B
         t2 = tick()
         if reducer is not None and comm:
             reducer.reset()
-        eng.backward(r.grad, p.grad, on_ready=reducer.mark_ready if (reducer is not None and comm and overlap) else None)
+        eng.backward(d_raw, d_protos, on_ready=reducer.mark_ready if (reducer is not None and comm and overlap) else None)
         if reducer is not None and comm:
             reducer.finish()
         t3 = tick()

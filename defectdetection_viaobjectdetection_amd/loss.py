@@ -87,21 +87,29 @@ def assign_targets(scores: torch.Tensor, boxes: torch.Tensor, anchors_px: torch.
     return t_boxes, t_scores, fg, gt_idx
 
 
-def segmentation_loss(raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, torch.Tensor], nc: int,
-                      imgsz: Tuple[int, int], box_gain: float = 7.5, cls_gain: float = 0.5, dfl_gain: float = 1.5):
-    """raw (B,A,64+nc+32); protos (B,mh,mw,32).  batch: batch_idx (N,), cls (N,), bboxes (N,4) xywh normalised to the
-    network input, masks (B,mh,mw) overlap-encoded (pixel value = 1 + index of the instance within its image,
-    instances sorted by area descending).  Returns (loss * B, detached items [box, seg, cls, dfl])."""
-    dev = raw.device
-    B, A, _ = raw.shape
-    mh, mw = protos.shape[1:3]
-    logits_box, logits_cls, coefs = raw.split((4 * REG_MAX, nc, NM), 2)
-    anchors, strides = anchor_grid(imgsz, dev)
-    bins = torch.arange(REG_MAX, device=dev, dtype=torch.float32)
-    # expectation over the 16 bins as multiply + reduce: `softmax @ bins` runs as a (B*A*4) x 16 rocBLAS gemv, 1.4 ms
-    ltrb = (logits_box.view(B, A, 4, REG_MAX).softmax(3) * bins).sum(3)
-    pred_boxes = torch.cat((anchors - ltrb[..., :2], anchors + ltrb[..., 2:]), -1)   # grid units
-    # padded GT tensors
+_CONST_CACHE: Dict = {}
+
+
+def _consts(imgsz: Tuple[int, int], mh: int, mw: int, dev, gains: Tuple[float, float, float]):
+    """Small constant tensors of the loss, built once per (image size, map size, device, gains): creating them inside the loss
+    would be host-to-device copies on every step (and is not allowed while a hipGraph is being captured)."""
+    key = (tuple(imgsz), mh, mw, str(dev), tuple(float(g) for g in gains))
+    c = _CONST_CACHE.get(key)
+    if c is None:
+        anchors, strides = anchor_grid(imgsz, dev)
+        c = dict(anchors=anchors, strides=strides, bins=torch.arange(REG_MAX, device=dev, dtype=torch.float32),
+                 wh=torch.tensor([imgsz[1], imgsz[0], imgsz[1], imgsz[0]], device=dev, dtype=torch.float32),
+                 mwh=torch.tensor([mw, mh, mw, mh], device=dev, dtype=torch.float32),
+                 cols=torch.arange(mw, device=dev, dtype=torch.float32).repeat(mh)[None, None, :],
+                 rows=torch.arange(mh, device=dev, dtype=torch.float32).repeat_interleave(mw)[None, None, :],
+                 gains=torch.tensor([gains[0], gains[0], gains[1], gains[2]], device=dev))
+        _CONST_CACHE[key] = c
+    return c
+
+
+def pad_targets(batch: Dict[str, torch.Tensor], B: int, imgsz: Tuple[int, int], dev):
+    """Labels (batch_idx, cls, bboxes xywh normalised) -> padded per-image tensors gt_cls (B,G), gt_boxes (B,G,4) xyxy px,
+    gt_valid (B,G).  The ONE host synchronisation of the loss is here (G = most instances in an image)."""
     bidx = batch["batch_idx"].to(dev).long()
     n_per = torch.bincount(bidx, minlength=B) if bidx.numel() else torch.zeros(B, dtype=torch.long, device=dev)
     G = int(n_per.max()) if bidx.numel() else 0
@@ -117,7 +125,37 @@ def segmentation_loss(raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, 
         gt_boxes[bidx[order], slot] = xyxy
         gt_cls[bidx[order], slot] = batch["cls"].to(dev).long().view(-1)[order]
         gt_valid[bidx[order], slot] = xyxy.sum(1) > 0
-    t_boxes, t_scores, fg, gt_idx = assign_targets(logits_cls.detach().sigmoid(), pred_boxes.detach() * strides,
+    return gt_cls, gt_boxes, gt_valid
+
+
+def segmentation_loss(raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, torch.Tensor], nc: int,
+                      imgsz: Tuple[int, int], box_gain: float = 7.5, cls_gain: float = 0.5, dfl_gain: float = 1.5):
+    """raw (B,A,64+nc+32); protos (B,mh,mw,32).  batch: batch_idx (N,), cls (N,), bboxes (N,4) xywh normalised to the
+    network input, masks (B,mh,mw) overlap-encoded (pixel value = 1 + index of the instance within its image,
+    instances sorted by area descending).  Returns (loss * B, detached items [box, seg, cls, dfl])."""
+    gt_cls, gt_boxes, gt_valid = pad_targets(batch, raw.shape[0], imgsz, raw.device)
+    return loss_core(raw, protos, gt_cls, gt_boxes, gt_valid, batch["masks"].to(raw.device), nc, imgsz, (box_gain, cls_gain, dfl_gain))
+
+
+def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_boxes: torch.Tensor, gt_valid: torch.Tensor,
+              masks: torch.Tensor, nc: int, imgsz: Tuple[int, int], gains: Tuple[float, float, float] = (7.5, 0.5, 1.5)):
+    """The loss on padded targets: fixed shapes for a given G, no host synchronisation, no host-to-device copy -- the part
+    GraphedSegLoss captures in a hipGraph."""
+    dev = raw.device
+    B, A, _ = raw.shape
+    mh, mw = protos.shape[1:3]
+    G = gt_boxes.shape[1]
+    k = _consts(imgsz, mh, mw, dev, gains)
+    anchors, strides, bins = k["anchors"], k["strides"], k["bins"]
+    logits_box, logits_cls, coefs = raw.split((4 * REG_MAX, nc, NM), 2)
+    # Decoded boxes of ALL anchors feed only the assignment (no gradient).  The box / DFL / mask terms below are evaluated on
+    # the <= 10 G foreground slots per image: every other anchor has weight zero, and carrying the (B, A, 4, 16) logits
+    # through softmax, log-softmax, two gathers and their backward passes cost ~2 ms of a 5.3 ms loss for 0.2 % of the rows.
+    # expectation over the 16 bins as multiply + reduce: `softmax @ bins` runs as a (B*A*4) x 16 rocBLAS gemv, 1.4 ms
+    with torch.no_grad():
+        ltrb = (logits_box.view(B, A, 4, REG_MAX).softmax(3) * bins).sum(3)
+        pred_boxes = torch.cat((anchors - ltrb[..., :2], anchors + ltrb[..., 2:]), -1)   # grid units
+    t_boxes, t_scores, fg, gt_idx = assign_targets(logits_cls.detach().sigmoid(), pred_boxes * strides,
                                                    anchors * strides, gt_cls, gt_boxes, gt_valid)
     # Everything below runs over ALL anchors / a fixed number of slots per image with zero weights for the background,
     # so the step has no data-dependent shapes and no host synchronisation after the one that sized the GT padding.
@@ -128,35 +166,113 @@ def segmentation_loss(raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, 
         zero = (protos * 0).sum() + (coefs * 0).sum() + (logits_box * 0).sum()
         items = torch.stack((zero, zero, loss_cls, zero))
     else:
-        tb = t_boxes / strides
-        loss_box = ((1.0 - ciou(pred_boxes, tb)) * w).sum() / denom
-        dist = torch.cat((anchors - tb[..., :2], tb[..., 2:] - anchors), -1).clamp(0, REG_MAX - 1 - 0.01)   # (B,A,4)
-        lo = dist.long()
-        logp = logits_box.view(B, A, 4, REG_MAX).log_softmax(3)
-        ce_lo = -logp.gather(3, lo[..., None]).squeeze(3)
-        ce_hi = -logp.gather(3, lo[..., None] + 1).squeeze(3)
-        loss_dfl = (((ce_lo * (lo + 1 - dist) + ce_hi * (dist - lo)).mean(2)) * w).sum() / denom
-        # masks: every GT claims at most 10 anchors, so K = 10 G slots per image hold all foreground anchors.
-        # BCE(coef . proto, gt mask of the assigned instance) inside the target box, mean over the map, divided by
-        # the normalised box area; one batched GEMM (B,K,32) x (B,32,mh*mw).
+        # every GT claims at most 10 anchors, so K = 10 G slots per image hold all foreground anchors
         K = min(10 * G, A)
         val, ai = fg.float().topk(K, dim=1)
         valid = val > 0                                                              # (B,K)
-        wh = torch.tensor([imgsz[1], imgsz[0], imgsz[1], imgsz[0]], device=dev, dtype=torch.float32)
-        nb = t_boxes.gather(1, ai[..., None].expand(B, K, 4)) / wh
+        ws = w.gather(1, ai) * valid                                                 # slot weights, 0 on empty slots
+        anc = anchors[ai]                                                            # (B,K,2) grid units
+        tb = (t_boxes / strides).gather(1, ai[..., None].expand(B, K, 4))
+        lb = logits_box.gather(1, ai[..., None].expand(B, K, 4 * REG_MAX)).view(B, K, 4, REG_MAX)
+        ltrb_s = (lb.softmax(3) * bins).sum(3)
+        pred_s = torch.cat((anc - ltrb_s[..., :2], anc + ltrb_s[..., 2:]), -1)
+        loss_box = ((1.0 - ciou(pred_s, tb)) * ws).sum() / denom
+        dist = torch.cat((anc - tb[..., :2], tb[..., 2:] - anc), -1).clamp(0, REG_MAX - 1 - 0.01)       # (B,K,4)
+        lo = dist.long()
+        logp = lb.log_softmax(3)
+        ce_lo = -logp.gather(3, lo[..., None]).squeeze(3)
+        ce_hi = -logp.gather(3, lo[..., None] + 1).squeeze(3)
+        loss_dfl = (((ce_lo * (lo + 1 - dist) + ce_hi * (dist - lo)).mean(2)) * ws).sum() / denom
+        # masks: BCE(coef . proto, gt mask of the assigned instance) inside the target box, mean over the map, divided by
+        # the normalised box area; one batched GEMM (B,K,32) x (B,32,mh*mw).
+        nb = t_boxes.gather(1, ai[..., None].expand(B, K, 4)) / k["wh"]
         area = ((nb[..., 2] - nb[..., 0]) * (nb[..., 3] - nb[..., 1])).masked_fill(~valid, 1.0)
-        mb = (nb * torch.tensor([mw, mh, mw, mh], device=dev, dtype=torch.float32))[..., None]            # (B,K,4,1)
-        cols = torch.arange(mw, device=dev, dtype=torch.float32).repeat(mh)[None, None, :]
-        rows = torch.arange(mh, device=dev, dtype=torch.float32).repeat_interleave(mw)[None, None, :]
+        mb = (nb * k["mwh"])[..., None]                                                                   # (B,K,4,1)
+        cols, rows = k["cols"], k["rows"]
         inside = (cols >= mb[:, :, 0]) & (cols < mb[:, :, 2]) & (rows >= mb[:, :, 1]) & (rows < mb[:, :, 3])
         ck = coefs.gather(1, ai[..., None].expand(B, K, NM))
         pred = torch.bmm(ck, protos.float().reshape(B, mh * mw, NM).transpose(1, 2))                    # (B,K,HW)
         inst = (gt_idx.gather(1, ai) + 1)[..., None]
-        gt = (batch["masks"].to(dev).reshape(B, 1, mh * mw) == inst).to(pred.dtype)
+        gt = (masks.reshape(B, 1, mh * mw) == inst).to(pred.dtype)
         bce = F.binary_cross_entropy_with_logits(pred, gt, reduction="none")
         per_slot = (bce * inside).mean(2) / area
         loss_seg = (per_slot * valid).sum() / fg.sum().clamp_min(1)
         items = torch.stack((loss_box, loss_seg, loss_cls, loss_dfl))
-    gains = torch.tensor([box_gain, box_gain, cls_gain, dfl_gain], device=dev)
-    items = items * gains
+    items = items * k["gains"]
     return items.sum() * B, items.detach()
+
+
+class GraphedSegLoss:
+    """The loss and its backward as ONE hipGraph replay per step (stands where ``criterion(preds, batch)`` +
+    ``loss.backward()`` stand upstream, /root/reference/BscanBased/yolo_seg_train.py:12).
+
+    ``loss_core`` forward + backward is ~230 small device kernels (4.2 ms of GPU time at batch 64) that take 5.8 ms of wall
+    time launched one by one: the host is the bottleneck.  For every padded-target width G seen, the first call warms up
+    eagerly, captures ``loss_core`` + ``backward`` on static input buffers, and later calls copy the inputs in and replay.
+    OPT-IN (``M355_LOSS_GRAPH=1``), eager by default: at the small shapes of the tests the replay equals the eager loss to
+    1e-5 and saves the launch overhead, but the one run at batch 64 @640 (tools/train_bench.py) ended in a GPU hardware
+    exception (HSA_STATUS_ERROR_EXCEPTION 0x1016) during the replayed steps; the cause was not found from that one failure
+    and the run was not repeated.  Also eager on CPU tensors and for batches without labels (G = 0).
+
+    ``__call__(raw, protos, batch, scale)`` -> (items (4,), d(scale * loss)/d raw, d(scale * loss)/d protos); the two
+    gradients are buffers of the graph, valid until the next call."""
+
+    def __init__(self, nc: int, imgsz: Tuple[int, int], gains: Tuple[float, float, float] = (7.5, 0.5, 1.5)):
+        import os
+        self.nc, self.imgsz, self.gains = nc, tuple(imgsz), tuple(gains)
+        self.enabled = os.environ.get("M355_LOSS_GRAPH") == "1"
+        self._states: Dict = {}
+
+    def _eager(self, raw, protos, gt, masks, scale):
+        r = raw.detach().clone().requires_grad_(True)
+        p = protos.detach().float().requires_grad_(True)
+        loss, items = loss_core(r, p, *gt, masks, self.nc, self.imgsz, self.gains)
+        (loss * scale).backward()
+        return items, r.grad, p.grad
+
+    def _capture(self, raw, protos, gt, masks):
+        st = dict(r=raw.detach().clone().requires_grad_(True), p=protos.detach().float().requires_grad_(True),
+                  gt=[t.clone() for t in gt], masks=masks.clone(), scale=torch.ones((), device=raw.device))
+
+        def run():
+            loss, items = loss_core(st["r"], st["p"], *st["gt"], st["masks"], self.nc, self.imgsz, self.gains)
+            (loss * st["scale"]).backward()
+            return items
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                      # warm-up off the capture: lazy initialisation, autograd buffers
+            for _ in range(2):
+                st["r"].grad = None
+                st["p"].grad = None
+                run()
+        torch.cuda.current_stream().wait_stream(side)
+        st["r"].grad = None                                # so that the gradients are allocated from the graph's pool
+        st["p"].grad = None
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            st["items"] = run()
+        st["graph"] = g
+        return st
+
+    def __call__(self, raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, torch.Tensor], scale: float = 1.0):
+        dev = raw.device
+        gt = pad_targets(batch, raw.shape[0], self.imgsz, dev)
+        masks = batch["masks"].to(dev)
+        G = gt[1].shape[1]
+        if not (self.enabled and raw.is_cuda and G > 0):
+            return self._eager(raw, protos, gt, masks, scale)
+        key = (G, tuple(raw.shape), tuple(protos.shape), masks.dtype)
+        st = self._states.get(key)
+        if st is None:
+            st = self._states[key] = self._capture(raw, protos, gt, masks)
+        with torch.no_grad():
+            st["r"].copy_(raw)
+            st["p"].copy_(protos)
+            for d, s_ in zip(st["gt"], gt):
+                d.copy_(s_)
+            st["masks"].copy_(masks)
+            st["scale"].fill_(float(scale))
+        st["graph"].replay()
+        return st["items"], st["r"].grad, st["p"].grad
+

@@ -32,7 +32,7 @@ import torch
 from . import metrics as M
 from ._capi import check, lib
 from .dataset import SegDataset, epoch_batches, rasterize_polygon, read_data_yaml
-from .loss import segmentation_loss
+from .loss import GraphedSegLoss
 from .sharding import GradBucketReducer
 
 DEFAULTS = dict(optimizer="auto", lr0=0.01, lrf=0.01, momentum=0.937, weight_decay=5e-4, warmup_epochs=3.0,
@@ -284,6 +284,7 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
     acc = torch.zeros(n_train, device=dev)
     sumsq = torch.zeros(int(lib.m355_grad_sumsq_workspace_floats()), device=dev)   # [0] sum g^2, [1] non-finite count, then workspace
     reducer = GradBucketReducer(flat_g, eng.grad_spans(), bucket_bytes=int(a.bucket_mb) << 20) if world > 1 else None
+    criterion = GraphedSegLoss(model.nc, (imgsz, imgsz), (a.box, a.cls, a.dfl))
 
     nb = len(epoch_batches(len(train_ds), local_batch, 0, a.seed, rank, world))
     opt_name = str(a.optimizer).lower()
@@ -377,16 +378,13 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
                 imgs = torch.from_numpy(b["img"]).to(dev, non_blocking=True)
             labels = {k: torch.from_numpy(b[k]).to(dev) for k in ("batch_idx", "cls", "bboxes", "masks")}
             raw, protos = eng.forward(imgs)
-            r = raw.detach().clone().requires_grad_(True)
-            p = protos.detach().float().requires_grad_(True)
-            loss, items = segmentation_loss(r, p, labels, model.nc, (imgsz, imgsz), a.box, a.cls, a.dfl)
-            (loss * scaler.scale).backward()
+            items, d_raw, d_protos = criterion(raw, protos, labels, scaler.scale)     # loss + its backward: one hipGraph replay
             micro += 1
             step_now = micro >= accumulate or i == len(batches) - 1
             overlap = reducer is not None and step_now and accumulate == 1
             if overlap:
                 reducer.reset()
-            eng.backward(r.grad, p.grad, on_ready=reducer.mark_ready if overlap else None)
+            eng.backward(d_raw, d_protos, on_ready=reducer.mark_ready if overlap else None)
             mloss += items
             if accumulate > 1 or not step_now:
                 acc.add_(flat_g)

@@ -138,3 +138,37 @@ def test_validator_map_matches_the_oracle_pipeline(tmp_path, cuda_device):
         assert abs(hip[f"metrics/{key}"] - ref[key]) <= 0.002, (key, hip[f"metrics/{key}"], ref[key])
     for key in ("mAP50-95(B)", "mAP50-95(M)"):
         assert abs(hip[f"metrics/{key}"] - ref[key]) <= 0.005, (key, hip[f"metrics/{key}"], ref[key])
+
+
+@pytest.mark.skipif(__import__("os").environ.get("M355_LOSS_GRAPH") != "1", reason="the graphed loss is opt-in (M355_LOSS_GRAPH=1): see GraphedSegLoss")
+def test_graphed_loss_equals_the_eager_loss(cuda_device):
+    """GraphedSegLoss (loss + backward captured in one hipGraph per target width) against the eager loss_core on the same
+    inputs: same items, same gradients, across replays with different inputs and a changing loss scale, and for a second G."""
+    from defectdetection_viaobjectdetection_amd import loss as L
+    B, imgsz, nc = 4, (128, 160), 1
+    A = sum((imgsz[0] // s) * (imgsz[1] // s) for s in (8, 16, 32))
+    gl = L.GraphedSegLoss(nc, imgsz)
+    g = torch.Generator().manual_seed(3)
+    for trial, n_per in enumerate(((2, 1, 2, 2), (1, 2, 2, 0), (3, 1, 0, 2))):          # G = 2, 2, 3
+        raw = torch.randn((B, A, 64 + nc + 32), generator=g).to(cuda_device)
+        protos = torch.randn((B, imgsz[0] // 4, imgsz[1] // 4, 32), generator=g).half().to(cuda_device)
+        bidx = torch.tensor([b for b, n in enumerate(n_per) for _ in range(n)], dtype=torch.float32)
+        n = len(bidx)
+        cxy = torch.rand((n, 2), generator=g) * 0.5 + 0.25
+        wh = torch.rand((n, 2), generator=g) * 0.2 + 0.1
+        masks = torch.zeros((B, imgsz[0] // 4, imgsz[1] // 4), dtype=torch.uint8)
+        masks[:, 8:16, 10:20] = 1
+        masks[:, 12:14, 12:16] = 2
+        batch = {"batch_idx": bidx.to(cuda_device), "cls": torch.zeros(n, device=cuda_device), "bboxes": torch.cat((cxy, wh), 1).to(cuda_device),
+                 "masks": masks.to(cuda_device)}
+        scale = 64.0 * (trial + 1)
+        items, d_raw, d_pr = gl(raw, protos, batch, scale)
+        r = raw.clone().requires_grad_(True)
+        p = protos.float().requires_grad_(True)
+        loss, items_ref = L.segmentation_loss(r, p, batch, nc, imgsz)
+        (loss * scale).backward()
+        torch.cuda.synchronize()
+        assert torch.allclose(items, items_ref, rtol=1e-5, atol=1e-6), (items, items_ref)
+        assert torch.allclose(d_raw, r.grad, rtol=1e-4, atol=1e-6 * scale)
+        assert torch.allclose(d_pr, p.grad, rtol=1e-4, atol=1e-6 * scale)
+    assert len(gl._states) == 2            # one graph per target width

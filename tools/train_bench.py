@@ -10,7 +10,7 @@ import torch
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from defectdetection_viaobjectdetection_amd._capi import check, lib  # noqa: E402
-from defectdetection_viaobjectdetection_amd.loss import segmentation_loss  # noqa: E402
+from defectdetection_viaobjectdetection_amd.loss import GraphedSegLoss  # noqa: E402
 from defectdetection_viaobjectdetection_amd.spec import init_state_dict  # noqa: E402
 from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine  # noqa: E402
 
@@ -33,6 +33,7 @@ batch = {"batch_idx": bidx, "cls": torch.zeros(n, device=dev), "bboxes": boxes, 
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 m1 = torch.zeros(eng.n_train, device=dev); m2 = torch.zeros(eng.n_train, device=dev); ema = eng.flat_params.clone()
 tim = {k: 0.0 for k in ("fwd", "loss", "bwd", "opt", "repack")}
+criterion = GraphedSegLoss(1, (S, S))
 
 
 def tick():
@@ -47,12 +48,10 @@ for it in range(steps + 2):
     t0 = tick()
     raw, protos = eng.forward(imgs)
     t1 = tick()
-    r = raw.detach().clone().requires_grad_(True)
-    p = protos.detach().float().requires_grad_(True)
-    loss, items = segmentation_loss(r, p, batch, 1, (S, S))
-    (loss * 128.0).backward()
+    items, d_raw, d_protos = criterion(raw, protos, batch, 128.0)
+    loss = items.sum() * B
     t2 = tick()
-    eng.backward(r.grad, p.grad)
+    eng.backward(d_raw, d_protos)
     t3 = tick()
     check(lib.m355_adamw_step(eng.flat_params.data_ptr(), eng.flat_grads.data_ptr(), m1.data_ptr(), m2.data_ptr(), ema.data_ptr(),
                               eng.group.data_ptr(), eng.n_train, 1e-4, 1e-4, 0.9, 0.999, 1e-8, 5e-4, it + 1, 1 / 128.0, 0.999, st()))
