@@ -439,6 +439,7 @@ class TrainEngine:
             if self.gtensors[i] is None:
                 self.gtensors[i] = torch.zeros_like(t)
         written: Dict[int, list] = {}                                     # tensor -> channel intervals written in this backward
+        level_bias: Dict[int, torch.Tensor] = {}                          # level offset -> per-channel sums of d_raw over the level
         self.gtensors[self.protos_t].copy_(d_protos.to(torch.float16))
         written[self.protos_t] = [(0, self.tensors[self.protos_t].shape[-1])]
         ready: List[str] = []
@@ -495,19 +496,30 @@ class TrainEngine:
                 h, w = op["hw"]
                 cout, cp = op["cout"], _ceil(op["cout"], 8)
                 lo = op["level_off"]
-                dz = torch.zeros((B, h * w, cp), dtype=torch.float16, device=self.dev)
-                dz[..., :cout] = d_raw[:, lo:lo + h * w, op["ch_off"]:op["ch_off"] + cout]
-                self.grads[f"{name}.bias"].copy_(dz[..., :cout].float().sum((0, 1)))
+                # fp16 copy of this conv's slice of d_raw in a persistent buffer (its padding channels stay zero); the bias
+                # gradients of a level's three output convs are ONE fp32 reduction over the level's rows of d_raw
+                dz = op.get("_dz")
+                if dz is None:
+                    dz = op["_dz"] = torch.zeros((B, h * w, cp), dtype=torch.float16, device=self.dev)
+                dz[..., :cout].copy_(d_raw[:, lo:lo + h * w, op["ch_off"]:op["ch_off"] + cout])
+                if lo not in level_bias:
+                    level_bias[lo] = d_raw[:, lo:lo + h * w, :].sum((0, 1))
+                self.grads[f"{name}.bias"].copy_(level_bias[lo][op["ch_off"]:op["ch_off"] + cout])
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
-                dw = torch.empty((cp, 1, 1, src.c), device=self.dev)
-                self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, dw)
-                self.grads[f"{name}.weight"].copy_(dw[:cout])
+                gw = self.grads[f"{name}.weight"]
+                if cp == cout:                                              # KRSC rows = the gradient's own layout: no staging copy
+                    self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, gw)
+                else:
+                    dw = op.get("_dw")
+                    if dw is None:
+                        dw = op["_dw"] = torch.empty((cp, 1, 1, src.c), device=self.dev)
+                    self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, dw)
+                    gw.copy_(dw[:cout])
                 ready += [f"{name}.bias", f"{name}.weight"]
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                 acc = 0 if self._claim(written, src) else gp
                 self._conv_launch(dz.data_ptr(), h * w * cp, cp, h, w, cp, self.packed[name + ":dgrad"], gp, gbs, ldg, h, w,
                                   src.c, 1, 1, 0, res_ptr=acc, r_bs=gbs, ldr=ldg)
-                op["_dz_keepalive"] = (dz, dw)
             elif kind == "convt":
                 name, src, dst = op["name"], op["src"], op["dst"]
                 tin = self.tensors[src.t]
