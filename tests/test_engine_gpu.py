@@ -461,3 +461,38 @@ def test_stem_fused_into_the_patch_kernel_matches_the_two_launches(cuda_device):
     print(f"stem fused vs two launches: raw head rel-L2 {e_raw:.2e}, prototypes rel-L2 {e_pr:.2e}")
     assert torch.isfinite(outs[0][2]).all()
     assert e_raw <= 2e-3 and e_pr <= 2e-3
+
+
+def test_two_engines_in_flight_give_the_sequential_results(cuda_device):
+    """bench.py's pipelining: two engine instances on two streams, forwards overlapping, each with its own activations, tile
+    queues and weights.  Every output must equal, bit for bit, what one engine computes alone for the same batch -- whatever
+    the overlap does to block placement and to the order in which persistent blocks claim their tiles."""
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    B = 8
+    batches = [torch.from_numpy(synthetic_bscans(B, seed=70 + j)).to(cuda_device) for j in range(4)]
+    ref_eng = SegEngine("s", 1, (640, 640), max_batch=B)
+    ref_eng.load_state_dict(sd)
+    refs = []
+    for x in batches:
+        p, q = ref_eng.forward(x)
+        torch.cuda.synchronize()
+        refs.append((p.clone(), q.clone()))
+    ref_eng.close()
+    engs = [SegEngine("s", 1, (640, 640), max_batch=B) for _ in range(2)]
+    for e in engs:
+        e.load_state_dict(sd)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [None] * len(batches)
+    for rep in range(3):                                   # several rounds: the queues are re-armed by every launch
+        for j, x in enumerate(batches):
+            e, s = engs[j % 2], streams[j % 2]
+            with torch.cuda.stream(s):
+                p, q = e.forward(x)
+                outs[j] = (p.clone(), q.clone())            # (clone on the same stream: ordered after the forward)
+        torch.cuda.synchronize()
+        for j in range(len(batches)):
+            assert torch.equal(outs[j][0], refs[j][0]) and torch.equal(outs[j][1], refs[j][1]), (rep, j)
+    for e in engs:
+        e.close()
