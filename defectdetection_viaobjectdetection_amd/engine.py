@@ -116,9 +116,12 @@ class SegEngine:
         return out
 
     def postprocess(self, preds: torch.Tensor, protos: Optional[torch.Tensor], conf: float = 0.25,
-                    iou: float = 0.7, max_det: int = 300, masks: bool = True):
+                    iou: float = 0.7, max_det: int = 300, masks: bool = True, multi_label: bool = False, max_nms: int = 30000):
         """Batched NMS + mask assembly.  Returns dets f32 (B,max_det,38), counts i32 (B),
-        masks u8 (B,max_det,H,W) or None.  Only rows < counts[b] are defined."""
+        masks u8 (B,max_det,H,W) or None.  Only rows < counts[b] are defined.
+        ``multi_label`` (upstream's validator mode, nc > 1): every (anchor, class) pair above ``conf`` is a candidate."""
+        if multi_label and self.nc > 1:
+            return self._postprocess_multilabel(preds, protos, conf, iou, max_det, masks, max_nms)
         B = preds.shape[0]
         dets = torch.empty((B, max_det, 6 + self.nm), dtype=torch.float32, device=preds.device)
         counts = torch.empty((B,), dtype=torch.int32, device=preds.device)
@@ -127,6 +130,39 @@ class SegEngine:
             m = torch.empty((B, max_det, self.imgsz[0], self.imgsz[1]), dtype=torch.uint8, device=preds.device)
         check(lib.m355_postprocess(self._h, _ptr(preds), _ptr(protos), B, conf, iou, max_det, _ptr(dets),
                                    _ptr(counts), _ptr(m), _stream()), self._h)
+        return dets, counts, m
+
+    def _postprocess_multilabel(self, preds, protos, conf, iou, max_det, masks, max_nms):
+        """upstream's ``non_max_suppression(multi_label=True)``: class offsets make the classes independent, so it is one
+        single-class NMS launch per class (the kernel and its bit-exact IoU arithmetic unchanged), the per-class survivors
+        merged in score order and cut at ``max_det``.  ``max_nms``: scores below an image's max_nms-th largest candidate
+        are masked out first (upstream keeps the top ``max_nms`` candidates of an image before the NMS)."""
+        B, A, _ = preds.shape
+        nc, nm = self.nc, self.nm
+        sc = preds[..., 4:4 + nc]
+        if A * nc > max_nms:
+            kth = sc.reshape(B, A * nc).topk(max_nms, dim=1).values[:, -1]                    # (B,)
+            sc = torch.where(sc >= kth[:, None, None], sc, torch.zeros_like(sc))
+        all_d, all_valid = [], []
+        for c in range(nc):
+            pc = torch.cat((preds[..., :4], sc[..., c:c + 1], preds[..., 4 + nc:]), -1).contiguous()
+            d = torch.empty((B, max_det, 6 + nm), dtype=torch.float32, device=preds.device)
+            n = torch.empty((B,), dtype=torch.int32, device=preds.device)
+            check(lib.m355_nms(_ptr(pc), B, A, 1, nm, conf, iou, max_det, _ptr(d), _ptr(n), _stream()))
+            d[..., 5] = float(c)
+            all_d.append(d)
+            all_valid.append(torch.arange(max_det, device=preds.device)[None, :] < n[:, None])
+        d = torch.cat(all_d, 1)                                                              # (B, nc * max_det, 6 + nm)
+        valid = torch.cat(all_valid, 1)
+        key = torch.where(valid, d[..., 4], torch.full_like(d[..., 4], -1.0))
+        order = key.argsort(dim=1, descending=True, stable=True)[:, :max_det]
+        dets = d.gather(1, order[..., None].expand(B, max_det, 6 + nm)).contiguous()
+        counts = valid.sum(1).clamp_max(max_det).to(torch.int32)
+        m = None
+        if masks:
+            m = torch.empty((B, max_det, self.imgsz[0], self.imgsz[1]), dtype=torch.uint8, device=preds.device)
+            check(lib.m355_proto_masks(_ptr(dets), _ptr(counts), _ptr(protos), B, max_det, self.proto_hw[0], self.proto_hw[1],
+                                       self.imgsz[0], self.imgsz[1], _ptr(m), _stream()))
         return dets, counts, m
 
     # ------------------------------------------------------------------ measurement hooks

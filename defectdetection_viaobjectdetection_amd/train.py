@@ -122,7 +122,8 @@ class Validator:
                 idx = list(range(i0, min(i0 + self.batch, n)))
                 x = torch.from_numpy(self.ds.images[idx]).to(dev)
                 preds, protos = self.engine.forward(x)
-                dets, counts, masks = self.engine.postprocess(preds, protos, self.conf, self.iou, self.max_det, masks=True)
+                dets, counts, masks = self.engine.postprocess(preds, protos, self.conf, self.iou, self.max_det, masks=True,
+                                                              multi_label=True)   # upstream's validator mode (a no-op for nc = 1)
                 counts_h = counts.cpu().tolist()
                 for j, i in enumerate(idx):
                     k = counts_h[j]

@@ -393,7 +393,7 @@ def nms_greedy(boxes: np.ndarray, iou_thr: float, max_keep: int) -> np.ndarray:
 
 
 def non_max_suppression(pred: np.ndarray, nc: int, conf_thres: float = 0.25, iou_thres: float = 0.7,
-                        max_det: int = 300, agnostic: bool = False) -> List[np.ndarray]:
+                        max_det: int = 300, agnostic: bool = False, multi_label: bool = False) -> List[np.ndarray]:
     """A11.  pred: (B, 4+nc+nm, A) float32.  Returns per image (n, 6+nm):
     [x1,y1,x2,y2,conf,cls, coefs...] sorted by confidence descending (ties: lower anchor index
     first -- a documented choice; upstream's ordering among exact ties is unspecified).
@@ -404,6 +404,23 @@ def non_max_suppression(pred: np.ndarray, nc: int, conf_thres: float = 0.25, iou
     for xi in range(pred.shape[0]):
         x = pred[xi].T  # (A, 4+nc+nm)
         scores = x[:, 4:4 + nc]
+        if multi_label and nc > 1:
+            # upstream's validator form (multi_label=True): EVERY (anchor, class) pair above the threshold is a candidate,
+            # in row-major (anchor, class) order; then the same sort / max_nms cap / class-offset NMS / max_det cut
+            ai, ci = np.nonzero(scores > np.float32(conf_thres))
+            if ai.size == 0:
+                out.append(np.zeros((0, 6 + x.shape[1] - 4 - nc), np.float32))
+                continue
+            pc = scores[ai, ci]
+            o = np.argsort(-pc, kind="stable")[:MAX_NMS]
+            ai, ci, pc = ai[o], ci[o], pc[o]
+            cx, cy, w, h = x[ai, 0], x[ai, 1], x[ai, 2], x[ai, 3]
+            hw, hh = w / np.float32(2), h / np.float32(2)
+            xyxy = np.stack((cx - hw, cy - hh, cx + hw, cy + hh), 1).astype(np.float32)
+            off = (ci.astype(np.float32) * np.float32(0.0 if agnostic else MAX_WH))[:, None]
+            keep = nms_greedy((xyxy + off).astype(np.float32), iou_thres, max_det)
+            out.append(np.concatenate((xyxy[keep], pc[keep, None], ci[keep, None].astype(np.float32), x[ai[keep], 4 + nc:]), 1).astype(np.float32))
+            continue
         conf = scores.max(1)
         cls = scores.argmax(1)  # first max on ties
         cand = np.nonzero(conf > np.float32(conf_thres))[0]

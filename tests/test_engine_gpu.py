@@ -496,3 +496,36 @@ def test_two_engines_in_flight_give_the_sequential_results(cuda_device):
             assert torch.equal(outs[j][0], refs[j][0]) and torch.equal(outs[j][1], refs[j][1]), (rep, j)
     for e in engs:
         e.close()
+
+
+def test_multi_label_postprocess_equals_the_oracle(cuda_device):
+    """The validator's NMS mode (upstream `non_max_suppression(multi_label=True)`): every (anchor, class) pair
+    above conf is a candidate.  Engine: one single-class NMS launch per class + merge; oracle: the joint class-offset NMS.
+    Same preds on both sides -> identical rows; masks of the merged detections against the oracle's process_mask."""
+    import yolov8_seg_oracle as orc
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    nc, B, imgsz = 3, 2, (320, 320)
+    eng = SegEngine("n", nc, imgsz, max_batch=B)
+    A = eng.num_anchors
+    g = torch.Generator().manual_seed(11)
+    cxy = torch.rand((B, A, 2), generator=g) * 280 + 20
+    wh = torch.rand((B, A, 2), generator=g) * 80 + 8
+    scores = torch.rand((B, A, nc), generator=g) ** 6                      # a few hundred pairs above 0.25, thousands above 0.001
+    coefs = torch.randn((B, A, 32), generator=g)
+    preds = torch.cat((cxy, wh, scores, coefs), -1).to(cuda_device)
+    protos = torch.randn((B, imgsz[0] // 4, imgsz[1] // 4, 32), generator=g).half().to(cuda_device)
+    for conf, iou, max_det in ((0.9, 0.7, 300), (0.25, 0.7, 300), (0.001, 0.6, 100)):     # below / at the max_det cut
+        dets, counts, masks = eng.postprocess(preds, protos, conf, iou, max_det, masks=True, multi_label=True)
+        torch.cuda.synchronize()
+        ref = orc.non_max_suppression(preds.cpu().permute(0, 2, 1).numpy(), nc, conf, iou, max_det, multi_label=True)
+        single = orc.non_max_suppression(preds.cpu().permute(0, 2, 1).numpy(), nc, conf, iou, max_det)
+        for b in range(B):
+            n = int(counts[b])
+            assert n == ref[b].shape[0], (conf, n, ref[b].shape)
+            assert np.array_equal(dets[b, :n].cpu().numpy(), ref[b]), (conf, b)
+            d = dets[b, :n].cpu()
+            want = orc.process_mask(protos[b].float().cpu().permute(2, 0, 1), d[:, 6:], d[:, :4], imgsz)
+            assert float((masks[b, :n].cpu().bool() == want).float().mean()) >= 0.995
+        print(f"conf {conf}: multi-label keeps {[int(c) for c in counts]}, best-class-per-anchor {[r.shape[0] for r in single]}")
+        assert len({int(c) for c in dets[0, :int(counts[0]), 5].tolist()}) > 1          # several classes survive
+    eng.close()

@@ -169,3 +169,20 @@ def test_scale_boxes_roundtrip():
     assert out[0].tolist() == pytest.approx([31.25, 6.25, 93.75, 75.0])
     out = orc.scale_boxes((640, 640), np.array([[-5.0, 0.0, 700.0, 700.0]], np.float32), (320, 320))
     assert out[0].tolist() == [0.0, 0.0, 320.0, 320.0]
+
+
+def test_nms_multi_label_keeps_one_row_per_anchor_class_pair():
+    """A11 in the validator's mode: an anchor with two classes above the threshold yields two candidates (same box, class
+    offsets keep them from suppressing each other); the best-class mode yields one."""
+    import numpy as np
+    import yolov8_seg_oracle as orc
+    nc, nm = 2, 4
+    pred = np.zeros((1, 4 + nc + nm, 3), np.float32)
+    pred[0, :4, 0] = (50, 50, 20, 20); pred[0, 4:6, 0] = (0.9, 0.6)        # both classes confident
+    pred[0, :4, 1] = (51, 50, 20, 20); pred[0, 4:6, 1] = (0.8, 0.1)        # overlaps anchor 0: suppressed in class 0
+    pred[0, :4, 2] = (150, 150, 20, 20); pred[0, 4:6, 2] = (0.2, 0.7)
+    one = orc.non_max_suppression(pred, nc, 0.25, 0.5, 300)[0]
+    multi = orc.non_max_suppression(pred, nc, 0.25, 0.5, 300, multi_label=True)[0]
+    assert one[:, 4].tolist() == [np.float32(0.9), np.float32(0.7)] and one[:, 5].tolist() == [0.0, 1.0]
+    assert multi[:, 4].tolist() == [np.float32(0.9), np.float32(0.7), np.float32(0.6)] and multi[:, 5].tolist() == [0.0, 1.0, 1.0]
+    assert np.array_equal(multi[0, :4], multi[2, :4])                      # the same anchor twice, once per class
