@@ -64,15 +64,25 @@ def average_precision(recall: np.ndarray, precision: np.ndarray) -> float:
     return float(np.sum((x[1:] - x[:-1]) * (y[1:] + y[:-1]) * 0.5))
 
 
+def _smooth(y: np.ndarray, f: float = 0.05) -> np.ndarray:
+    """Box filter of fraction f (upstream ``utils.metrics.smooth``; edges padded with the end values)."""
+    nf = round(len(y) * f * 2) // 2 + 1
+    pad = np.ones(nf // 2)
+    yp = np.concatenate((pad * y[0], y, pad * y[-1]), 0)
+    return np.convolve(yp, np.ones(nf) / nf, mode="valid")
+
+
 def ap_per_class(tp: np.ndarray, conf: np.ndarray, pred_cls: np.ndarray, gt_cls: np.ndarray) -> Dict[str, np.ndarray]:
-    """tp (n,10); returns per-class AP (nc_present,10), precision / recall at the best-F1 confidence, classes."""
+    """tp (n,10); returns per-class AP (nc_present,10), precision / recall and the classes.  Precision / recall are read
+    where upstream reads them: at ONE confidence for all classes, the argmax of the smoothed class-mean F1 curve over 1000
+    confidence points (``ap_per_class`` upstream: ``i = smooth(f1_curve.mean(0), 0.1).argmax()``)."""
     order = np.argsort(-conf, kind="stable")
     tp, conf, pred_cls = tp[order], conf[order], pred_cls[order]
     classes, n_gt = np.unique(gt_cls.astype(np.int64), return_counts=True)
     ap = np.zeros((classes.size, tp.shape[1]))
-    prec = np.zeros(classes.size)
-    rec = np.zeros(classes.size)
     grid = np.linspace(0, 1, 1000)
+    p_curve = np.zeros((classes.size, grid.size))
+    r_curve = np.zeros((classes.size, grid.size))
     for ci, c in enumerate(classes):
         sel = pred_cls == c
         if not sel.any():
@@ -83,12 +93,11 @@ def ap_per_class(tp: np.ndarray, conf: np.ndarray, pred_cls: np.ndarray, gt_cls:
         precision = tpc / (tpc + fpc)
         for t in range(tp.shape[1]):
             ap[ci, t] = average_precision(recall[:, t], precision[:, t])
-        r = np.interp(-grid, -conf[sel], recall[:, 0], left=0)
-        p = np.interp(-grid, -conf[sel], precision[:, 0], left=1)
-        f1 = 2 * p * r / (p + r + 1e-16)
-        k = int(f1.argmax())
-        prec[ci], rec[ci] = p[k], r[k]
-    return {"ap": ap, "precision": prec, "recall": rec, "classes": classes}
+        r_curve[ci] = np.interp(-grid, -conf[sel], recall[:, 0], left=0)
+        p_curve[ci] = np.interp(-grid, -conf[sel], precision[:, 0], left=1)
+    f1 = 2 * p_curve * r_curve / (p_curve + r_curve + 1e-16)
+    k = int(_smooth(f1.mean(0), 0.1).argmax()) if classes.size else 0
+    return {"ap": ap, "precision": p_curve[:, k], "recall": r_curve[:, k], "classes": classes}
 
 
 def summarize(tp: np.ndarray, conf: np.ndarray, pred_cls: np.ndarray, gt_cls: np.ndarray) -> Tuple[float, float, float, float]:
