@@ -306,8 +306,8 @@ def train_step_bench(world, dist, steps=4, warm=2):
     masks = torch.zeros(B, S // 4, S // 4, device=dev)
     masks[:, 40:80, 40:80] = 1
     masks[:, 60:70, 60:70] = 2
-    batch = {"batch_idx": torch.arange(B).repeat_interleave(2).float().to(dev), "cls": torch.zeros(n, device=dev), "bboxes": boxes,
-             "masks": masks}
+    # labels as a loader hands them over: the small per-instance tensors on the host, the mask maps already on the device
+    batch = {"batch_idx": torch.arange(B).repeat_interleave(2).float(), "cls": torch.zeros(n), "bboxes": boxes.cpu(), "masks": masks}
     criterion = GraphedSegLoss(1, (S, S))
     m1 = torch.zeros(eng.n_train, device=dev)
     m2 = torch.zeros(eng.n_train, device=dev)
@@ -320,27 +320,32 @@ def train_step_bench(world, dist, steps=4, warm=2):
         return time.perf_counter()
 
     def one_step(it, tim, overlap=True, comm=True):
-        t0 = tick()
+        """One step as a training loop runs it: the host synchronises ONCE, at the end (reading the loss); the phase times are
+        device times between events on the stream (an idle device waiting for the host counts in the phase it waits in)."""
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+        prep = criterion.prepare(batch, B, dev)                           # padded targets before the forward is enqueued
+        ev[0].record()
         raw, protos = eng.forward(imgs)
-        t1 = tick()
-        items, d_raw, d_protos = criterion(raw, protos, batch, 128.0)     # loss + backward of the loss: one hipGraph replay
-        loss = items.sum() * B
-        t2 = tick()
+        ev[1].record()
+        items, d_raw, d_protos = criterion(raw, protos, prep, 128.0)      # loss + backward of the loss
+        ev[2].record()
         if reducer is not None and comm:
             reducer.reset()
         eng.backward(d_raw, d_protos, on_ready=reducer.mark_ready if (reducer is not None and comm and overlap) else None)
         if reducer is not None and comm:
             reducer.finish()
-        t3 = tick()
+        ev[3].record()
         check(lib.m355_adamw_step(eng.flat_params.data_ptr(), eng.flat_grads.data_ptr(), m1.data_ptr(), m2.data_ptr(), ema.data_ptr(),
                                   eng.group.data_ptr(), eng.n_train, 1e-4, 1e-4, 0.9, 0.999, 1e-8, 5e-4, it + 1, 1 / (128.0 * world), 0.999,
                                   st()))
-        t4 = tick()
+        ev[4].record()
         eng.repack()
-        t5 = tick()
-        for k, v in zip(("fwd", "loss", "bwd", "opt", "repack"), (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
-            tim[k] = tim.get(k, 0.0) + v
-        return float(loss)
+        ev[5].record()
+        loss = float(items.sum() * B)                                     # the step's host synchronisation
+        ev[5].synchronize()
+        for j, k in enumerate(("fwd", "loss", "bwd", "opt", "repack")):
+            tim[k] = tim.get(k, 0.0) + ev[j].elapsed_time(ev[j + 1]) * 1e-3
+        return loss
 
     def run(overlap, comm):
         tim = {}

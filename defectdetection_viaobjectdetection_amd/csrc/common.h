@@ -165,6 +165,12 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
                       const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s);
 // floats of workspace the train-mode batch-norm launches need for C channels (per-block partial sums + ticket)
 size_t bn_workspace_floats(int C);
+// gradient glue of the training step (train_kernels.hip): fixed-order column sums, nearest-2x upsample backward, input conversion
+long colsum_workspace_floats(long nb, int cols);
+int launch_colsum(const void* src, int src_f16, long nb, long bstride, long rows, int ld, int cols, float* ws, float* out, hipStream_t s);
+int launch_upsample2x_bwd(const half_t* g, long g_bs, int ldg, half_t* d, long d_bs, int ldd, int B, int H, int W, int C, int accumulate,
+                          hipStream_t s);
+int launch_u8_to_f16x8(const unsigned char* src, half_t* dst, long npx, hipStream_t s);
 int launch_repack(const void* d_jobs /* m355_repack_job[] (include/mi355yolo.h) */, const int* d_block_job, int nblocks, hipStream_t s);
 
 // train-mode BatchNorm + SiLU (train_kernels.hip)

@@ -1807,6 +1807,26 @@ int m355_sppf_pool_bwd_launch(const void* a, int64_t a_bstride, int32_t lda, con
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "sppf backward launch failed: " + std::to_string(rc));
 }
 
+int64_t m355_colsum_workspace_floats(int64_t nb, int32_t cols) { return colsum_workspace_floats(nb, cols); }
+
+int m355_colsum_launch(const void* src, int32_t src_f16, int64_t nb, int64_t bstride, int64_t rows, int32_t ld, int32_t cols, float* ws,
+                       float* out, void* stream) {
+  const int rc = launch_colsum(src, src_f16, nb, bstride, rows, ld, cols, ws, out, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "column-sum launch failed: " + std::to_string(rc));
+}
+
+int m355_upsample2x_bwd_launch(const void* g, int64_t g_bstride, int32_t ldg, void* d, int64_t d_bstride, int32_t ldd, int32_t B,
+                               int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream) {
+  const int rc = launch_upsample2x_bwd((const half_t*)g, g_bstride, ldg, (half_t*)d, d_bstride, ldd, B, H, W, C, accumulate,
+                                       (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "upsample backward launch failed: " + std::to_string(rc));
+}
+
+int m355_u8_to_f16x8_launch(const uint8_t* src, void* dst, int64_t npx, void* stream) {
+  const int rc = launch_u8_to_f16x8(src, (half_t*)dst, npx, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "input conversion launch failed: " + std::to_string(rc));
+}
+
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

@@ -591,4 +591,178 @@ int launch_repack(const void* d_jobs, const int* d_block_job, int nblocks, hipSt
   return (int)hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Gradient glue of the training step.  Each of these stood as 2-4 strided torch kernels with an fp32 copy of the
+// whole tensor in between (rocprofv3 sequence of one step, tools/trace_seq.py): the bias gradients of the head's output
+// convs and of the ConvTranspose as `x.float().sum(dims)` (0.7 + 0.5 ms for 0.3 GB of reads), the backward of the nearest
+// 2x upsample as `.float().sum((2, 4))` + add (0.4 ms), the uint8 -> fp16 input conversion as four passes (0.55 ms).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int CS_BLOCKS = 2048;   // target number of partial rows of a column sum
+
+// Partial column sums of rows [blockIdx.x * chunk, +chunk) of batch blockIdx.y of a (nb, rows, cols) fp32 view: thread t owns
+// column t % cols on row lane t / cols (256 / cols lanes), adds its rows in order; the lanes are added in lane order.
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float* src, long bstride, long rows, int ld, int cols, long chunk,
+                                                         float* ws) {
+  __shared__ float red[256];
+  const int rl = 256 / cols;
+  const int c = threadIdx.x % cols, l = threadIdx.x / cols;
+  const long r0 = blockIdx.x * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  const float* const p = src + blockIdx.y * bstride + c;
+  float acc = 0.f;
+  if (l < rl) {
+    long r = r0 + l;
+    for (; r + 3 * rl < r1; r += 4 * rl) {
+      const float v0 = p[r * ld], v1 = p[(r + rl) * ld], v2 = p[(r + 2 * rl) * ld], v3 = p[(r + 3 * rl) * ld];
+      acc += v0; acc += v1; acc += v2; acc += v3;
+    }
+    for (; r < r1; r += rl) acc += p[r * ld];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (threadIdx.x < cols) {
+    float t = 0.f;
+    for (int k = 0; k < rl; ++k) t += red[k * cols + threadIdx.x];
+    ws[WS_HEAD + ((long)blockIdx.y * gridDim.x + blockIdx.x) * cols + threadIdx.x] = t;
+  }
+}
+
+// The same over an fp16 view with cols % 8 == 0: a thread owns an 8-channel group (16-byte loads), fp32 accumulators.
+__global__ __launch_bounds__(256) void colsum_f16_kernel(const half_t* src, long bstride, long rows, int ld, int cols, long chunk,
+                                                         float* ws) {
+  __shared__ float red[256 * 8];
+  const int cg = cols / 8, rl = 256 / cg;
+  const int g = threadIdx.x % cg, l = threadIdx.x / cg;
+  const long r0 = blockIdx.x * chunk, r1 = r0 + chunk < rows ? r0 + chunk : rows;
+  const half_t* const p = src + blockIdx.y * bstride + g * 8;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (l < rl) {
+    long r = r0 + l;
+    for (; r + 7 * rl < r1; r += 8 * rl) {
+      half8 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = *(const half8*)(p + (r + (long)u * rl) * ld);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += (float)v[u][j];
+    }
+    for (; r < r1; r += rl) {
+      const half8 v = *(const half8*)(p + r * ld);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = acc[j];
+  __syncthreads();
+  for (int t = threadIdx.x; t < cols; t += 256) {
+    const int gg = t >> 3, j = t & 7;
+    float sum = 0.f;
+    for (int k = 0; k < rl; ++k) sum += red[(k * cg + gg) * 8 + j];
+    ws[WS_HEAD + ((long)blockIdx.y * gridDim.x + blockIdx.x) * cols + t] = sum;
+  }
+}
+
+// d[b][y][x][c] (=|+=) g[b][2y][2x][c] + g[b][2y][2x+1][c] + g[b][2y+1][2x][c] + g[b][2y+1][2x+1][c]: the four taps are added in
+// fp32 in that order and rounded to fp16 once; accumulate adds that fp16 value to what d holds (fp32 add, one rounding) -- the
+// arithmetic of `gs = g.float().sum(...)`, `d.copy_(gs)` / `d.add_(gs.half())`.
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const half_t* g, long g_bs, int ldg, half_t* d, long d_bs, int ldd, int H,
+                                                             int W, int C, int accumulate, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int cg = C / 8;
+  const int c8 = (int)(e % cg);
+  const long px = e / cg;
+  const int x = (int)(px % W);
+  const long by = px / W;
+  const int y = (int)(by % H);
+  const long b = by / H;
+  const half_t* gp = g + b * g_bs + ((long)(2 * y) * (2 * W) + 2 * x) * ldg + c8 * 8;
+  const half8 v00 = *(const half8*)gp, v01 = *(const half8*)(gp + ldg);
+  const half8 v10 = *(const half8*)(gp + (long)2 * W * ldg), v11 = *(const half8*)(gp + (long)2 * W * ldg + ldg);
+  half_t* dp = d + b * d_bs + ((long)y * W + x) * ldd + c8 * 8;
+  half8 o;
+  if (accumulate) {
+    const half8 old = *(const half8*)dp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      o[j] = m355_to_half((float)old[j] + (float)m355_to_half((((float)v00[j] + (float)v01[j]) + (float)v10[j]) + (float)v11[j]));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = m355_to_half((((float)v00[j] + (float)v01[j]) + (float)v10[j]) + (float)v11[j]);
+  }
+  *(half8*)dp = o;
+}
+
+// (N, 3) uint8 pixels -> (N, 8) fp16 rows [r/255, g/255, b/255, 0, 0, 0, 0, 0] (correctly rounded fp32 division, then one
+// rounding to fp16 = `(u8.float() / 255).half()`).  A block converts 1024 pixels: their 3072 bytes go through LDS as coalesced
+// dwords, then thread t writes pixels t, t + 256, ... so that a wave's store is 1 KB of consecutive rows.
+__global__ __launch_bounds__(256) void u8_to_f16x8_kernel(const unsigned char* src, half_t* dst, long npx, int aligned) {
+  __shared__ unsigned int stage[768];
+  const long p0 = (long)blockIdx.x * 1024;
+  const int np = npx - p0 >= 1024 ? 1024 : (int)(npx - p0);
+  const unsigned char* const s = src + p0 * 3;
+  unsigned char* const sb = (unsigned char*)stage;
+  if (aligned && np == 1024) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) stage[k * 256 + threadIdx.x] = ((const unsigned int*)s)[k * 256 + threadIdx.x];
+  } else {
+    for (int i = threadIdx.x; i < np * 3; i += 256) sb[i] = s[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = k * 256 + threadIdx.x;
+    if (p >= np) break;
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (half_t)0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = m355_to_half(__fdiv_rn((float)sb[p * 3 + j], 255.0f));
+    *(half8*)(dst + (p0 + p) * 8) = o;
+  }
+}
+}  // namespace
+
+long colsum_workspace_floats(long nb, int cols) { return WS_HEAD + (nb > CS_BLOCKS ? nb : (long)CS_BLOCKS) * cols; }
+
+// out[c] = sum over (b, r) of src[b * bstride + r * ld + c], c < cols, in a fixed order (partial rows + bn_finalize_kernel).
+int launch_colsum(const void* src, int src_f16, long nb, long bstride, long rows, int ld, int cols, float* ws, float* out,
+                  hipStream_t s) {
+  if (!src || !ws || !out || nb < 1 || rows < 1 || cols < 1 || ld < cols) return -1;
+  if (src_f16 ? (cols % 8 || ld % 8 || cols > 2048) : cols > 256) return -1;
+  const int rl = src_f16 ? 256 / (cols / 8) : 256 / cols;
+  long bpb = CS_BLOCKS / nb;                                 // blocks per batch entry: <= CS_BLOCKS rows in all (or nb of them)
+  const long most = (rows + 8L * rl - 1) / (8L * rl);        // at least eight rows per lane
+  if (bpb > most) bpb = most;
+  if (bpb < 1) bpb = 1;
+  const long chunk = (rows + bpb - 1) / bpb;
+  bpb = (rows + chunk - 1) / chunk;
+  if (src_f16)
+    hipLaunchKernelGGL(colsum_f16_kernel, dim3((unsigned)bpb, (unsigned)nb), dim3(256), 0, s, (const half_t*)src, bstride, rows, ld, cols,
+                       chunk, ws);
+  else
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)bpb, (unsigned)nb), dim3(256), 0, s, (const float*)src, bstride, rows, ld, cols,
+                       chunk, ws);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((cols + 63) / 64), dim3(FIN_WAVES * 64), 0, s, ws, cols, (int)(bpb * nb), out);
+  return (int)hipGetLastError();
+}
+
+int launch_upsample2x_bwd(const half_t* g, long g_bs, int ldg, half_t* d, long d_bs, int ldd, int B, int H, int W, int C, int accumulate,
+                          hipStream_t s) {
+  if (!g || !d || C % 8 || ldg % 8 || ldd % 8 || B < 1 || H < 1 || W < 1) return -1;
+  const long total = (long)B * H * W * (C / 8);
+  hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, g_bs, ldg, d, d_bs, ldd, H, W, C,
+                     accumulate, total);
+  return (int)hipGetLastError();
+}
+
+int launch_u8_to_f16x8(const unsigned char* src, half_t* dst, long npx, hipStream_t s) {
+  if (!src || !dst || npx < 1) return -1;
+  hipLaunchKernelGGL(u8_to_f16x8_kernel, dim3((unsigned)((npx + 1023) / 1024)), dim3(256), 0, s, src, dst, npx,
+                     (int)(((unsigned long)src & 3) == 0));
+  return (int)hipGetLastError();
+}
+
 }  // namespace m355

@@ -255,9 +255,19 @@ class GraphedSegLoss:
         st["graph"] = g
         return st
 
+    def prepare(self, batch: Dict[str, torch.Tensor], B: int, dev) -> Dict[str, torch.Tensor]:
+        """The padded targets of a batch, to be made BEFORE the forward pass is enqueued and handed to ``__call__`` in place of
+        the batch.  ``pad_targets`` holds the loss's one host synchronisation (the padded width G): on host labels it runs on
+        the CPU and only the three padded tensors are uploaded; on device labels it waits for an idle stream instead of for
+        the whole forward pass -- either way the host can enqueue the ~500 small kernels of the loss while the device is still
+        in the forward convolutions."""
+        dev = torch.device(dev)
+        gt = pad_targets(batch, B, self.imgsz, batch["batch_idx"].device)
+        return {"_gt": tuple(t.to(dev, non_blocking=True) for t in gt), "masks": batch["masks"].to(dev, non_blocking=True)}
+
     def __call__(self, raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, torch.Tensor], scale: float = 1.0):
         dev = raw.device
-        gt = pad_targets(batch, raw.shape[0], self.imgsz, dev)
+        gt = batch["_gt"] if "_gt" in batch else pad_targets(batch, raw.shape[0], self.imgsz, dev)
         masks = batch["masks"].to(dev)
         G = gt[1].shape[1]
         if not (self.enabled and raw.is_cuda and G > 0):

@@ -377,9 +377,10 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
             else:
                 b = train_ds.batch(idx, flip=rng.random(len(idx)) < a.fliplr)
                 imgs = torch.from_numpy(b["img"]).to(dev, non_blocking=True)
-            labels = {k: torch.from_numpy(b[k]).to(dev) for k in ("batch_idx", "cls", "bboxes", "masks")}
+            # targets padded on the host before the forward is enqueued: the loss then needs no synchronisation of its own
+            labels = criterion.prepare({k: torch.from_numpy(b[k]) for k in ("batch_idx", "cls", "bboxes", "masks")}, eng.B, dev)
             raw, protos = eng.forward(imgs)
-            items, d_raw, d_protos = criterion(raw, protos, labels, scaler.scale)     # loss + its backward: one hipGraph replay
+            items, d_raw, d_protos = criterion(raw, protos, labels, scaler.scale)     # loss + its backward
             micro += 1
             step_now = micro >= accumulate or i == len(batches) - 1
             overlap = reducer is not None and step_now and accumulate == 1

@@ -59,6 +59,7 @@ class TrainEngine:
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.dev)
         self.zero_bias = torch.zeros(4096, dtype=torch.float32, device=self.dev)
         self.wgrad_ws = torch.empty(1 << 20, dtype=torch.float32, device=self.dev)   # split-K partial slabs (deterministic wgrad)
+        self._colsum_ws = None                                                       # partial rows of the bias-gradient column sums
         self._build()
 
     # ------------------------------------------------------------------ graph
@@ -290,6 +291,26 @@ class TrainEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    def _padded_bias(self, op, name: str) -> torch.Tensor:
+        """The bias of a plain conv followed by 128 zeros (the kernels read whole channel tiles): a persistent buffer refreshed
+        with one copy per step."""
+        b = self.params[f"{name}.bias"]
+        buf = op.get("_bias_pad")
+        if buf is None:
+            buf = op["_bias_pad"] = torch.zeros(b.numel() + 128, dtype=torch.float32, device=self.dev)
+        buf[:b.numel()].copy_(b)
+        return buf
+
+    def _colsum(self, src_ptr: int, f16: bool, nb: int, bstride: int, rows: int, ld: int, cols: int, out: torch.Tensor) -> torch.Tensor:
+        """out[c] = sum over (b, r) of src[b * bstride + r * ld + c] in a fixed order (bias gradients); out fp32 contiguous."""
+        need = int(lib.m355_colsum_workspace_floats(nb, cols))
+        if self._colsum_ws is None or self._colsum_ws.numel() < need:
+            self._colsum_ws = torch.empty(need, dtype=torch.float32, device=self.dev)
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == cols
+        check(lib.m355_colsum_launch(src_ptr, 1 if f16 else 0, nb, bstride, rows, ld, cols, self._colsum_ws.data_ptr(), out.data_ptr(),
+                                     self._stream()))
+        return out
+
     def _slice_ptr(self, tensors, sl: Slice):
         t = tensors[sl.t]
         return t.data_ptr() + sl.off * t.element_size(), t.shape[1] * t.shape[2] * t.shape[3], t.shape[3]
@@ -327,8 +348,9 @@ class TrainEngine:
         B = self.B
         assert tuple(images_u8_nhwc.shape) == (B, *self.imgsz, 3) and images_u8_nhwc.dtype == torch.uint8
         x8 = self.tensors[self.x8]
-        x8[..., :3] = (images_u8_nhwc.float() / 255.0).half()
         st = self._stream()
+        # (u8 / 255) -> fp16 into the 8-channel input rows in one pass (was float(), div, half(), strided copy: 0.55 ms at b64)
+        check(lib.m355_u8_to_f16x8_launch(images_u8_nhwc.contiguous().data_ptr(), x8.data_ptr(), x8.numel() // 8, st))
         for op in self.ops:
             kind = op["kind"]
             if kind == "conv":
@@ -364,20 +386,18 @@ class TrainEngine:
                 h, w = op["hw"]
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 yp = self.raw.data_ptr() + (op["level_off"] * self.rw + op["ch_off"]) * 4
-                bias = F.pad(self.params[f"{name}.bias"], (0, 128))
+                bias = self._padded_bias(op, name)
                 self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, self.A * self.rw, self.rw, h, w,
                                   op["cout"], 1, 1, 0, bias=bias, out_f32=1)
-                op["_bias_keepalive"] = bias
             elif kind == "convt":
                 name, src, dst = op["name"], op["src"], op["dst"]
                 tin, tout = self.tensors[src.t], self.tensors[dst.t]
                 h, w = tin.shape[1:3]
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
-                bias = F.pad(self.params[f"{name}.bias"], (0, 128))
+                bias = self._padded_bias(op, name)
                 self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, ybs, ldy, h, w, 4 * dst.c, 1, 1, 0,
                                   bias=bias, convt_co=dst.c)
-                op["_bias_keepalive"] = bias
             elif kind == "pool":
                 src, dst = op["src"], op["dst"]
                 t = self.tensors[src.t]
@@ -435,6 +455,7 @@ class TrainEngine:
         parameter's gradient have been enqueued (GradBucketReducer.mark_ready: the all-reduce is stream-ordered)."""
         B = self.B
         st = self._stream()
+        d_raw = d_raw.float().contiguous()                                  # no-ops for the loss's own gradient buffer
         for i, t in enumerate(self.tensors):
             if self.gtensors[i] is None:
                 self.gtensors[i] = torch.zeros_like(t)
@@ -503,7 +524,8 @@ class TrainEngine:
                     dz = op["_dz"] = torch.zeros((B, h * w, cp), dtype=torch.float16, device=self.dev)
                 dz[..., :cout].copy_(d_raw[:, lo:lo + h * w, op["ch_off"]:op["ch_off"] + cout])
                 if lo not in level_bias:
-                    level_bias[lo] = d_raw[:, lo:lo + h * w, :].sum((0, 1))
+                    level_bias[lo] = self._colsum(d_raw.data_ptr() + lo * d_raw.shape[2] * 4, False, B, d_raw.shape[1] * d_raw.shape[2],
+                                                  h * w, d_raw.shape[2], d_raw.shape[2], torch.empty(d_raw.shape[2], device=self.dev))
                 self.grads[f"{name}.bias"].copy_(level_bias[lo][op["ch_off"]:op["ch_off"] + cout])
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 gw = self.grads[f"{name}.weight"]
@@ -527,7 +549,7 @@ class TrainEngine:
                 cin, cout = src.c, dst.c
                 self._ensure(written, dst)
                 gy = self.gtensors[dst.t]                                   # (B, 2h, 2w, cout) contiguous, own tensor
-                self.grads[f"{name}.bias"].copy_(gy.float().sum((0, 1, 2)))
+                self._colsum(gy.data_ptr(), True, 1, 0, B * 4 * h * w, cout, cout, self.grads[f"{name}.bias"])
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 # wgrad of the equivalent 2x2 / stride-2 conv (dY -> X): "dz" = X, "x" = dY -> [cin][(dy,dx),co]
                 dw = torch.empty((cin, 2, 2, cout), device=self.dev)
@@ -566,13 +588,11 @@ class TrainEngine:
             elif kind == "up":
                 src, dst = op["src"], op["dst"]
                 self._ensure(written, dst)
-                g = self._gview(dst)
-                Bq, H2, W2, c = g.shape
-                gs = g.reshape(Bq, H2 // 2, 2, W2 // 2, 2, c).float().sum((2, 4))
-                if self._claim(written, src):
-                    self._gview(src).copy_(gs)
-                else:
-                    self._gview(src).add_(gs.half())
+                hs, ws_ = self.tensors[src.t].shape[1:3]
+                gyp, gybs, ldgy = self._slice_ptr(self.gtensors, dst)
+                gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
+                check(lib.m355_upsample2x_bwd_launch(gyp, gybs, ldgy, gp, gbs, ldg, B, hs, ws_, src.c,
+                                                     0 if self._claim(written, src) else 1, st))
         if on_ready is not None:
             for k in ready:
                 on_ready(k)

@@ -237,6 +237,20 @@ int m355_sppf_pool_bwd_launch(const void* a, int64_t a_bstride, int32_t lda, con
                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream);
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* Gradient glue of the training step (each replaces a strided torch expression reached from yolo_seg_train.py:12's backward):
+ *  colsum: out[c] = sum over b < nb, r < rows of src[b * bstride + r * ld + c] for c < cols, fp32 result, fixed summation order
+ *    (bias gradients: `d_raw[:, lo:hi, :].sum((0, 1))`, `gy.float().sum((0, 1, 2))`).  src fp32 (cols <= 256) or fp16 (src_f16 = 1:
+ *    cols and ld multiples of 8, cols <= 2048); strides in elements; ws: m355_colsum_workspace_floats(nb, cols) floats.
+ *  upsample2x_bwd: d (B,H,W,C) = or += the 2x2 sums of g (B,2H,2W,C) (fp32 sum of the four taps, one rounding to fp16;
+ *    accumulate = 1 adds that fp16 value to d).  C, ldg, ldd multiples of 8.
+ *  u8_to_f16x8: (npx, 3) uint8 -> (npx, 8) fp16 rows [r/255, g/255, b/255, 0 x5] = `(u8.float() / 255).half()`, the 8-channel
+ *    input buffer of the training stem. */
+int64_t m355_colsum_workspace_floats(int64_t nb, int32_t cols);
+int m355_colsum_launch(const void* src, int32_t src_f16, int64_t nb, int64_t bstride, int64_t rows, int32_t ld, int32_t cols, float* ws,
+                       float* out, void* stream);
+int m355_upsample2x_bwd_launch(const void* g, int64_t g_bstride, int32_t ldg, void* d, int64_t d_bstride, int32_t ldd, int32_t B,
+                               int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream);
+int m355_u8_to_f16x8_launch(const uint8_t* src, void* dst, int64_t npx, void* stream);
 
 /* Optimizer step over a flat fp32 parameter buffer (replaces torch.optim.AdamW / SGD + ModelEMA.update reached from
  * /root/reference/BscanBased/yolo_seg_train.py:12).  group[i]: 0 decayed weights, 1 norm weights, 2 biases (lr_bias).

@@ -1,6 +1,7 @@
 """Backward building blocks (SURVEY A13 backward) vs PyTorch autograd on the CPU (fp32 on fp16-rounded operands)."""
 import ctypes as C
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -162,3 +163,79 @@ def test_sppf_pool_backward_matches_autograd(B, H, W, Cc, acc, cuda_device):
     torch.cuda.synchronize()
     want = (old.float() + ga_ref.half().float()).half() if acc else ga_ref.half()
     assert torch.equal(d_ga.cpu(), want), float((d_ga.cpu().float() - want.float()).abs().max())
+
+
+@pytest.mark.parametrize("f16,nb,rows,cols,ld", [(0, 4, 1600, 97, 97), (0, 64, 100, 97, 97), (0, 3, 37, 145, 160), (0, 1, 5, 256, 256),
+                                                  (1, 1, 51200, 64, 64), (1, 2, 333, 32, 96), (1, 5, 7, 512, 512)])
+def test_column_sums_match_torch_and_repeat_bit_for_bit(f16, nb, rows, cols, ld, cuda_device):
+    """Bias gradients: m355_colsum_launch against `x.float().sum(rows)` on a (nb, rows, cols) view of a wider,
+    batch-strided buffer -- fp32 tolerance (another summation order), the second run the same bits (fixed order)."""
+    from defectdetection_viaobjectdetection_amd import _capi as capi
+    g = torch.Generator().manual_seed(11)
+    A = rows + 9                                                           # the view is rows [4, 4 + rows) of each batch entry
+    full = torch.randn((nb, A, ld), generator=g)
+    full = (full.half() if f16 else full).to(cuda_device)
+    view = full[:, 4:4 + rows, :cols]
+    ws = torch.empty(int(capi.lib.m355_colsum_workspace_floats(nb, cols)), device=cuda_device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for _ in range(2):
+        out = torch.full((cols,), float("nan"), device=cuda_device)
+        capi.check(capi.lib.m355_colsum_launch(full.data_ptr() + 4 * ld * full.element_size(), f16, nb, A * ld, rows, ld, cols, _p(ws),
+                                               _p(out), st))
+        torch.cuda.synchronize()
+        outs.append(out.cpu())
+    want = view.double().sum((0, 1)).cpu()
+    scale = view.double().abs().sum((0, 1)).cpu()
+    assert torch.equal(outs[0], outs[1])
+    assert float(((outs[0].double() - want).abs() / scale).max()) < 2e-6
+    # invalid shapes are refused, not launched
+    assert capi.lib.m355_colsum_launch(_p(full), f16, nb, A * ld, rows, ld, 4096 if f16 else 300, _p(ws), _p(out), st) != 0
+
+
+@pytest.mark.parametrize("B,H,W,Cc,acc", [(2, 20, 20, 64, 0), (3, 7, 5, 24, 1), (1, 1, 1, 8, 1)])
+def test_upsample_backward_equals_the_torch_expression(B, H, W, Cc, acc, cuda_device):
+    """Nearest-2x upsample backward on channel slices of wider buffers (the concat tensors of the neck) against
+    `g.reshape(B, H, 2, W, 2, C).float().sum((2, 4))` stored / added as fp16.  Values on a 2^-6 grid: the fp32 sum of four is exact
+    whatever its order, so the comparison is bit for bit; a second case with normal values bounds the order effect to one fp16 ulp."""
+    from defectdetection_viaobjectdetection_amd import _capi as capi
+    gen = torch.Generator().manual_seed(3)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for exact in (True, False):
+        gfull = torch.randn((B, 2 * H, 2 * W, Cc + 16), generator=gen)
+        gfull = ((gfull * 64).round() / 64 if exact else gfull).half()
+        dfull = torch.randn((B, H, W, Cc + 8), generator=gen).half()
+        gs = gfull[..., 8:8 + Cc].reshape(B, H, 2, W, 2, Cc).float().sum((2, 4))
+        want = dfull.clone()
+        want[..., 8:] = (dfull[..., 8:].float() + gs.half().float()).half() if acc else gs.half()
+        d_g, d_d = gfull.to(cuda_device), dfull.clone().to(cuda_device)
+        capi.check(capi.lib.m355_upsample2x_bwd_launch(d_g.data_ptr() + 16, 4 * H * W * (Cc + 16), Cc + 16, d_d.data_ptr() + 16,
+                                                       H * W * (Cc + 8), Cc + 8, B, H, W, Cc, acc, st))
+        torch.cuda.synchronize()
+        got = d_d.cpu()
+        assert torch.equal(got[..., :8], dfull[..., :8])                     # channels outside the slice untouched
+        if exact:
+            assert torch.equal(got, want)
+        else:
+            assert float((got.float() - want.float()).abs().max()) <= 2 ** -9 * float(want.float().abs().max())
+
+
+@pytest.mark.parametrize("npx", [1, 3, 4, 1027, 64 * 64 * 2])
+def test_input_conversion_equals_float_div_255_half(npx, cuda_device):
+    """uint8 pixels -> the 8-channel fp16 input rows of the training stem: every byte value, bit for bit against
+    `(u8.float() / 255).half()` computed on the host (IEEE division), channels 3..7 zero; also from a source pointer that is not
+    4-byte aligned."""
+    from defectdetection_viaobjectdetection_amd import _capi as capi
+    gen = torch.Generator().manual_seed(9)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for shift in (0, 1):
+        src = torch.randint(0, 256, (npx * 3 + shift,), generator=gen, dtype=torch.uint8)
+        if npx * 3 >= 256:
+            src[shift:shift + 256] = torch.arange(256, dtype=torch.uint8)
+        d_src = src.to(cuda_device)
+        out = torch.full((npx, 8), float("nan"), dtype=torch.float16, device=cuda_device)
+        capi.check(capi.lib.m355_u8_to_f16x8_launch(d_src.data_ptr() + shift, _p(out), npx, st))
+        torch.cuda.synchronize()
+        want = torch.zeros((npx, 8), dtype=torch.float16)
+        want[:, :3] = torch.from_numpy((src[shift:].view(npx, 3).numpy().astype(np.float32) / np.float32(255.0)).astype(np.float16))
+        assert torch.equal(out.cpu(), want)

@@ -100,3 +100,16 @@ def test_assigner_picks_at_most_one_gt_per_anchor():
     g = gt[0][idx[0][fg[0]]]
     assert bool(((a > g[:, :2]) & (a < g[:, 2:])).all())      # every positive anchor centre lies inside its GT
     assert float(ts.max()) <= 1.0 + 1e-5 and float(ts[~fg].abs().sum()) == 0
+
+
+def test_targets_prepared_ahead_give_the_same_loss_and_gradients():
+    """GraphedSegLoss.prepare (the padded targets made before the forward pass is enqueued, train.py) + __call__ on the prepared
+    dict == __call__ on the batch itself, items and both gradients bit for bit; also for a batch with an image without labels."""
+    for empty in (False, True):
+        raw, protos, batch, _ = _case(4, 3, 2, (64, 96), 3, empty)
+        crit = L.GraphedSegLoss(2, (64, 96))
+        i1, gr1, gp1 = crit(raw, protos, batch, 8.0)
+        prep = crit.prepare(batch, 3, "cpu")
+        assert set(prep) == {"_gt", "masks"} and prep["_gt"][1].shape[0] == 3
+        i2, gr2, gp2 = crit(raw, protos, prep, 8.0)
+        assert torch.equal(i1, i2) and torch.equal(gr1, gr2) and torch.equal(gp1, gp2)

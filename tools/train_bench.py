@@ -29,7 +29,8 @@ boxes = torch.tensor(np.stack([rng.uniform(.3, .7, n), rng.uniform(.3, .7, n), r
 masks = torch.zeros(B, S // 4, S // 4, device=dev)
 masks[:, 40:80, 40:80] = 1
 masks[:, 60:70, 60:70] = 2
-batch = {"batch_idx": bidx, "cls": torch.zeros(n, device=dev), "bboxes": boxes, "masks": masks}
+# labels as a loader hands them over: the small per-instance tensors on the host, the mask maps already on the device
+batch = {"batch_idx": bidx.cpu(), "cls": torch.zeros(n), "bboxes": boxes.cpu(), "masks": masks}
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)  # noqa: E731
 m1 = torch.zeros(eng.n_train, device=dev); m2 = torch.zeros(eng.n_train, device=dev); ema = eng.flat_params.clone()
 tim = {k: 0.0 for k in ("fwd", "loss", "bwd", "opt", "repack")}
@@ -45,21 +46,25 @@ for it in range(steps + 2):
     if it == 2:
         tim = {k: 0.0 for k in tim}
         t_all = tick()
-    t0 = tick()
+    # as a training loop runs it: one host synchronisation per step (reading the loss); phases = device time between events
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    prep = criterion.prepare(batch, B, dev)
+    ev[0].record()
     raw, protos = eng.forward(imgs)
-    t1 = tick()
-    items, d_raw, d_protos = criterion(raw, protos, batch, 128.0)
-    loss = items.sum() * B
-    t2 = tick()
+    ev[1].record()
+    items, d_raw, d_protos = criterion(raw, protos, prep, 128.0)
+    ev[2].record()
     eng.backward(d_raw, d_protos)
-    t3 = tick()
+    ev[3].record()
     check(lib.m355_adamw_step(eng.flat_params.data_ptr(), eng.flat_grads.data_ptr(), m1.data_ptr(), m2.data_ptr(), ema.data_ptr(),
                               eng.group.data_ptr(), eng.n_train, 1e-4, 1e-4, 0.9, 0.999, 1e-8, 5e-4, it + 1, 1 / 128.0, 0.999, st()))
-    t4 = tick()
+    ev[4].record()
     eng.repack()
-    t5 = tick()
-    for k, v in zip(tim, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
-        tim[k] += v
+    ev[5].record()
+    loss = float(items.sum() * B)
+    ev[5].synchronize()
+    for j, k in enumerate(tim):
+        tim[k] += ev[j].elapsed_time(ev[j + 1]) * 1e-3
 total = tick() - t_all
-print(f"yolov8{scale}-seg train b{B} {S}x{S}: {total / steps * 1e3:.1f} ms/step = {B * steps / total:.1f} img/s; loss {float(loss):.3f}")
+print(f"yolov8{scale}-seg train b{B} {S}x{S}: {total / steps * 1e3:.1f} ms/step = {B * steps / total:.1f} img/s; loss {loss:.3f}")
 print("  " + "  ".join(f"{k} {v / steps * 1e3:.1f} ms" for k, v in tim.items()))
