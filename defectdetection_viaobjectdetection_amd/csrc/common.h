@@ -171,6 +171,9 @@ int launch_colsum(const void* src, int src_f16, long nb, long bstride, long rows
 int launch_upsample2x_bwd(const half_t* g, long g_bs, int ldg, half_t* d, long d_bs, int ldd, int B, int H, int W, int C, int accumulate,
                           hipStream_t s);
 int launch_u8_to_f16x8(const unsigned char* src, half_t* dst, long npx, hipStream_t s);
+// mask term of the segmentation loss + its gradients in one pass (loss_kernels.hip)
+int launch_mask_loss(const float* coef, const void* protos, int protos_f16, const int* masks, const int* inst, const float* boxes,
+                     const float* w, int B, int K, int mh, int mw, float* slot_sum, float* d_coef, float* d_protos, hipStream_t s);
 int launch_repack(const void* d_jobs /* m355_repack_job[] (include/mi355yolo.h) */, const int* d_block_job, int nblocks, hipStream_t s);
 
 // train-mode BatchNorm + SiLU (train_kernels.hip)

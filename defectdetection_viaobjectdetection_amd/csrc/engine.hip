@@ -1827,6 +1827,14 @@ int m355_u8_to_f16x8_launch(const uint8_t* src, void* dst, int64_t npx, void* st
   return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "input conversion launch failed: " + std::to_string(rc));
 }
 
+int m355_mask_loss_launch(const float* coef, const void* protos, int32_t protos_f16, const int32_t* masks, const int32_t* inst,
+                          const float* boxes, const float* weights, int32_t B, int32_t K, int32_t mh, int32_t mw, float* slot_sum,
+                          float* d_coef, float* d_protos, void* stream) {
+  const int rc = launch_mask_loss(coef, protos, protos_f16, masks, inst, boxes, weights, B, K, mh, mw, slot_sum, d_coef, d_protos,
+                                  (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "mask-loss launch failed: " + std::to_string(rc));
+}
+
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

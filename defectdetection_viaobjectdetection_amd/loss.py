@@ -137,6 +137,44 @@ def segmentation_loss(raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, 
     return loss_core(raw, protos, gt_cls, gt_boxes, gt_valid, batch["masks"].to(raw.device), nc, imgsz, (box_gain, cls_gain, dfl_gain))
 
 
+def _mask_kernel_enabled() -> bool:
+    import os
+    return os.environ.get("M355_NO_MASK_KERNEL") != "1"
+
+
+class _MaskTerm(torch.autograd.Function):
+    """sum_{b,k} w[b,k] * mean_p(BCE(coef[b,k] . proto[b,p], mask[b,p] == inst[b,k]) inside box[b,k]) with both gradients from
+    ONE device pass (``m355_mask_loss_launch``): the gradients need only forward values, so they are computed with the value
+    and scaled by the incoming gradient in ``backward``.  coef (B,K,32) fp32; protos (B,mh,mw,32) fp16 or fp32; masks
+    (B,mh,mw) overlap-encoded; inst (B,K); boxes (B,K,4) prototype px; w (B,K), 0 = skip the slot."""
+
+    @staticmethod
+    def forward(ctx, coef, protos, masks, inst, boxes, w):
+        import ctypes as C
+        from ._capi import check, lib
+        B, K, _ = coef.shape
+        mh, mw = protos.shape[1:3]
+        assert protos.shape[3] == NM and protos.dtype in (torch.float16, torch.float32)
+        coef_c, protos_c = coef.detach().float().contiguous(), protos.detach().contiguous()
+        masks_i, inst_i = masks.to(torch.int32).contiguous(), inst.to(torch.int32).contiguous()
+        boxes_c, w_c = boxes.float().contiguous(), w.float().contiguous()
+        slot_sum = torch.empty((B, K), dtype=torch.float32, device=coef.device)
+        d_coef = torch.empty((B, K, NM), dtype=torch.float32, device=coef.device)
+        d_protos = torch.empty((B, mh, mw, NM), dtype=torch.float32, device=coef.device)
+        check(lib.m355_mask_loss_launch(coef_c.data_ptr(), protos_c.data_ptr(), 1 if protos.dtype == torch.float16 else 0,
+                                        masks_i.data_ptr(), inst_i.data_ptr(), boxes_c.data_ptr(), w_c.data_ptr(), B, K, mh, mw,
+                                        slot_sum.data_ptr(), d_coef.data_ptr(), d_protos.data_ptr(),
+                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        ctx.save_for_backward(d_coef, d_protos)
+        ctx.protos_dtype = protos.dtype
+        return (slot_sum * w_c).sum() / float(mh * mw)
+
+    @staticmethod
+    def backward(ctx, g):
+        d_coef, d_protos = ctx.saved_tensors
+        return d_coef * g, (d_protos * g).to(ctx.protos_dtype), None, None, None, None
+
+
 def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_boxes: torch.Tensor, gt_valid: torch.Tensor,
               masks: torch.Tensor, nc: int, imgsz: Tuple[int, int], gains: Tuple[float, float, float] = (7.5, 0.5, 1.5)):
     """The loss on padded targets: fixed shapes for a given G, no host synchronisation, no host-to-device copy -- the part
@@ -187,16 +225,22 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
         # the normalised box area; one batched GEMM (B,K,32) x (B,32,mh*mw).
         nb = t_boxes.gather(1, ai[..., None].expand(B, K, 4)) / k["wh"]
         area = ((nb[..., 2] - nb[..., 0]) * (nb[..., 3] - nb[..., 1])).masked_fill(~valid, 1.0)
-        mb = (nb * k["mwh"])[..., None]                                                                   # (B,K,4,1)
-        cols, rows = k["cols"], k["rows"]
-        inside = (cols >= mb[:, :, 0]) & (cols < mb[:, :, 2]) & (rows >= mb[:, :, 1]) & (rows < mb[:, :, 3])
+        mbox = nb * k["mwh"]                                                                              # (B,K,4) prototype px
         ck = coefs.gather(1, ai[..., None].expand(B, K, NM))
-        pred = torch.bmm(ck, protos.float().reshape(B, mh * mw, NM).transpose(1, 2))                    # (B,K,HW)
-        inst = (gt_idx.gather(1, ai) + 1)[..., None]
-        gt = (masks.reshape(B, 1, mh * mw) == inst).to(pred.dtype)
-        bce = F.binary_cross_entropy_with_logits(pred, gt, reduction="none")
-        per_slot = (bce * inside).mean(2) / area
-        loss_seg = (per_slot * valid).sum() / fg.sum().clamp_min(1)
+        inst = gt_idx.gather(1, ai) + 1
+        nfg = fg.sum().clamp_min(1)
+        if raw.is_cuda and _mask_kernel_enabled():
+            # one HIP pass over the boxes' pixels gives the term and both gradients (csrc/loss_kernels.hip)
+            loss_seg = _MaskTerm.apply(ck, protos, masks, inst, mbox.detach(), (valid / (area * nfg)).detach())
+        else:
+            mb = mbox[..., None]                                                                          # (B,K,4,1)
+            cols, rows = k["cols"], k["rows"]
+            inside = (cols >= mb[:, :, 0]) & (cols < mb[:, :, 2]) & (rows >= mb[:, :, 1]) & (rows < mb[:, :, 3])
+            pred = torch.bmm(ck, protos.float().reshape(B, mh * mw, NM).transpose(1, 2))                # (B,K,HW)
+            gt = (masks.reshape(B, 1, mh * mw) == inst[..., None]).to(pred.dtype)
+            bce = F.binary_cross_entropy_with_logits(pred, gt, reduction="none")
+            per_slot = (bce * inside).mean(2) / area
+            loss_seg = (per_slot * valid).sum() / nfg
         items = torch.stack((loss_box, loss_seg, loss_cls, loss_dfl))
     items = items * k["gains"]
     return items.sum() * B, items.detach()
@@ -225,7 +269,9 @@ class GraphedSegLoss:
 
     def _eager(self, raw, protos, gt, masks, scale):
         r = raw.detach().clone().requires_grad_(True)
-        p = protos.detach().float().requires_grad_(True)
+        # on the device the prototypes stay fp16 (the engine's own buffer): the mask kernel reads them as they are and the
+        # gradient comes back in the dtype TrainEngine.backward stores anyway
+        p = (protos.detach() if protos.is_cuda else protos.detach().float()).requires_grad_(True)
         loss, items = loss_core(r, p, *gt, masks, self.nc, self.imgsz, self.gains)
         (loss * scale).backward()
         return items, r.grad, p.grad

@@ -252,6 +252,18 @@ int m355_upsample2x_bwd_launch(const void* g, int64_t g_bstride, int32_t ldg, vo
                                int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream);
 int m355_u8_to_f16x8_launch(const uint8_t* src, void* dst, int64_t npx, void* stream);
 
+/* Mask term of the segmentation loss with its gradients, forward and backward in one pass (replaces
+ * v8SegmentationLoss.single_mask_loss and its autograd, reached from /root/reference/BscanBased/yolo_seg_train.py:12).
+ * For slot k of image b (a foreground anchor): pred[p] = coef[b,k,:] . protos[b,p,:] over 32 channels,
+ * slot_sum[b,k] = sum over the pixels p with x1 <= col < x2, y1 <= row < y2 of BCEWithLogits(pred[p], masks[b,p] == inst[b,k]);
+ * with L = (1 / (mh mw)) sum_{b,k} weights[b,k] slot_sum[b,k]:  d_coef = dL/dcoef (B,K,32), d_protos = dL/dprotos (B,mh,mw,32)
+ * fp32, every element written.  protos (B,mh,mw,32) NHWC fp16 (protos_f16 = 1) or fp32; masks (B,mh,mw) int32
+ * overlap-encoded; boxes (B,K,4) x1,y1,x2,y2 in prototype pixels; a slot with weight 0 is skipped (its outputs are 0).
+ * No float atomics: bitwise reproducible. */
+int m355_mask_loss_launch(const float* coef, const void* protos, int32_t protos_f16, const int32_t* masks, const int32_t* inst,
+                          const float* boxes, const float* weights, int32_t B, int32_t K, int32_t mh, int32_t mw, float* slot_sum,
+                          float* d_coef, float* d_protos, void* stream);
+
 /* Optimizer step over a flat fp32 parameter buffer (replaces torch.optim.AdamW / SGD + ModelEMA.update reached from
  * /root/reference/BscanBased/yolo_seg_train.py:12).  group[i]: 0 decayed weights, 1 norm weights, 2 biases (lr_bias).
  * grad_mul = clip_coef / loss_scale.  ema may be NULL.  step counts from 1 (Adam bias correction). */

@@ -172,3 +172,75 @@ def test_graphed_loss_equals_the_eager_loss(cuda_device):
         assert torch.allclose(d_raw, r.grad, rtol=1e-4, atol=1e-6 * scale)
         assert torch.allclose(d_pr, p.grad, rtol=1e-4, atol=1e-6 * scale)
     assert len(gl._states) == 2            # one graph per target width
+
+
+def test_mask_term_kernel_equals_the_torch_expression(cuda_device, monkeypatch):
+    """csrc/loss_kernels.hip through the loss against the torch-op form of the same term on the same device tensors (fp16
+    prototypes as the engine hands them over): items, d raw, d protos; and the kernel twice = the same bits."""
+    from defectdetection_viaobjectdetection_amd import loss as L
+    for seed, B, nc, imgsz, n_inst, empty in ((5, 6, 1, (192, 256), 3, False), (6, 3, 3, (128, 128), 5, True)):
+        raw, protos, batch, _ = _case(seed, B, nc, imgsz, n_inst, empty)
+        dbatch = {k: v.to(cuda_device) for k, v in batch.items()}
+        res = {}
+        for mode in ("kernel", "kernel2", "torch"):
+            monkeypatch.setenv("M355_NO_MASK_KERNEL", "1" if mode == "torch" else "0")
+            r = raw.to(cuda_device).requires_grad_(True)
+            p = protos.half().to(cuda_device).requires_grad_(True)
+            lp, ip = L.segmentation_loss(r, p, dbatch, nc, imgsz)
+            (lp * 64.0).backward()
+            torch.cuda.synchronize()
+            res[mode] = (ip.cpu(), r.grad.cpu(), p.grad.float().cpu())
+        assert all(torch.equal(a, b) for a, b in zip(res["kernel"], res["kernel2"]))
+        ik, grk, gpk = res["kernel"]
+        it, grt, gpt = res["torch"]
+        np.testing.assert_allclose(ik.numpy(), it.numpy(), rtol=2e-5, atol=1e-7)
+        assert float((grk - grt).norm() / grt.norm()) <= 1e-5
+        # d protos leaves in fp16 on both paths: one rounding each
+        assert float((gpk - gpt).norm() / gpt.norm()) <= 1e-3
+        assert float(gpt.abs().max()) > 0
+
+
+def test_mask_loss_abi_edge_cases(cuda_device):
+    """m355_mask_loss_launch directly: boxes partly / wholly outside the map, an empty box, a zero-weight slot with garbage in
+    its box, fp32 and fp16 prototypes -- against the dense torch expression in float64."""
+    import ctypes as C
+    from defectdetection_viaobjectdetection_amd import _capi as capi
+    g = torch.Generator().manual_seed(1)
+    B, K, mh, mw = 2, 6, 24, 40
+    coef = torch.randn(B, K, 32, generator=g)
+    masks = torch.randint(0, 4, (B, mh, mw), generator=g, dtype=torch.int32)
+    inst = torch.randint(1, 4, (B, K), generator=g, dtype=torch.int32)
+    boxes = torch.tensor([[3.2, 2.0, 17.5, 9.9], [-5.0, -3.0, 12.0, 30.0], [35.5, 20.1, 60.0, 24.0], [10.0, 10.0, 10.0, 12.0],
+                          [50.0, 5.0, 70.0, 9.0], [float("nan"), 0.0, 1e30, -1e30]]).repeat(B, 1, 1)
+    w = torch.rand(B, K, generator=g) + 0.5
+    w[:, 5] = 0.0
+    cols = torch.arange(mw, dtype=torch.float32).repeat(mh)[None, None]
+    rows = torch.arange(mh, dtype=torch.float32).repeat_interleave(mw)[None, None]
+    bx = boxes[..., None]
+    inside = (cols >= bx[:, :, 0]) & (cols < bx[:, :, 2]) & (rows >= bx[:, :, 1]) & (rows < bx[:, :, 3])
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for f16 in (0, 1):
+        protos = torch.randn(B, mh, mw, 32, generator=g)
+        protos = protos.half() if f16 else protos
+        c64 = coef.double().requires_grad_(True)
+        p64 = protos.double().requires_grad_(True)
+        pred = torch.bmm(c64, p64.reshape(B, mh * mw, 32).transpose(1, 2))
+        gt = (masks.reshape(B, 1, -1) == inst[..., None]).double()
+        bce = torch.nn.functional.binary_cross_entropy_with_logits(pred, gt, reduction="none")
+        ssum = (bce * inside).sum(2)
+        (ssum * w.double() * (w != 0)).sum().div(mh * mw).backward()
+        d = lambda t: t.contiguous().to(cuda_device)  # noqa: E731
+        dc, dp, dm, di, db, dw = d(coef), d(protos), d(masks), d(inst), d(boxes), d(w)
+        o_sum = torch.full((B, K), float("nan"), device=cuda_device)
+        o_dc = torch.full((B, K, 32), float("nan"), device=cuda_device)
+        o_dp = torch.full((B, mh, mw, 32), float("nan"), device=cuda_device)
+        capi.check(capi.lib.m355_mask_loss_launch(dc.data_ptr(), dp.data_ptr(), f16, dm.data_ptr(), di.data_ptr(), db.data_ptr(),
+                                                  dw.data_ptr(), B, K, mh, mw, o_sum.data_ptr(), o_dc.data_ptr(), o_dp.data_ptr(), st))
+        torch.cuda.synchronize()
+        want_sum = (ssum * (w != 0)).detach()
+        np.testing.assert_allclose(o_sum.cpu().double().numpy(), want_sum.numpy(), rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(o_dc.cpu().double().numpy(), c64.grad.numpy(), rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(o_dp.cpu().double().numpy(), p64.grad.numpy(), rtol=1e-4, atol=1e-8)
+        assert float(o_sum[:, 3].abs().max()) == 0.0 and float(o_sum[:, 4].abs().max()) == 0.0      # empty / outside boxes
+    assert capi.lib.m355_mask_loss_launch(dc.data_ptr(), dp.data_ptr(), 1, dm.data_ptr(), di.data_ptr(), db.data_ptr(), dw.data_ptr(),
+                                          B, 0, mh, mw, o_sum.data_ptr(), o_dc.data_ptr(), o_dp.data_ptr(), st) != 0
