@@ -174,6 +174,10 @@ int launch_u8_to_f16x8(const unsigned char* src, half_t* dst, long npx, hipStrea
 // mask term of the segmentation loss + its gradients in one pass (loss_kernels.hip)
 int launch_mask_loss(const float* coef, const void* protos, int protos_f16, const int* masks, const int* inst, const float* boxes,
                      const float* w, int B, int K, int mh, int mw, float* slot_sum, float* d_coef, float* d_protos, hipStream_t s);
+int launch_box_loss(const float* logits, const float* anchors, const float* targets, const float* weights, long n, float* box_term,
+                    float* dfl_term, float* d_box, float* d_dfl, hipStream_t s);
+int launch_dfl_decode(const float* raw, long rows, int A, int rw, int nc, const float* anchors, const float* strides, float* boxes,
+                      float* scores, hipStream_t s);
 int launch_repack(const void* d_jobs /* m355_repack_job[] (include/mi355yolo.h) */, const int* d_block_job, int nblocks, hipStream_t s);
 
 // train-mode BatchNorm + SiLU (train_kernels.hip)

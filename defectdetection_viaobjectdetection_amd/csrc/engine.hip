@@ -1835,6 +1835,18 @@ int m355_mask_loss_launch(const float* coef, const void* protos, int32_t protos_
   return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "mask-loss launch failed: " + std::to_string(rc));
 }
 
+int m355_box_loss_launch(const float* logits, const float* anchors, const float* targets, const float* weights, int64_t n,
+                         float* box_term, float* dfl_term, float* d_box, float* d_dfl, void* stream) {
+  const int rc = launch_box_loss(logits, anchors, targets, weights, n, box_term, dfl_term, d_box, d_dfl, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "box-loss launch failed: " + std::to_string(rc));
+}
+
+int m355_dfl_decode_launch(const float* raw, int64_t rows, int32_t A, int32_t rw, int32_t nc, const float* anchors, const float* strides,
+                           float* boxes, float* scores, void* stream) {
+  const int rc = launch_dfl_decode(raw, rows, A, rw, nc, anchors, strides, boxes, scores, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "dfl-decode launch failed: " + std::to_string(rc));
+}
+
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

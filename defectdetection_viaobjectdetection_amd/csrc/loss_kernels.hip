@@ -170,6 +170,182 @@ __global__ __launch_bounds__(256) void mask_loss_proto_kernel(const float* coef,
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// Box (CIoU) and DFL terms on the foreground slots, value and gradient w.r.t. the 4 x 16 distribution logits of a slot in one
+// pass (upstream: BboxLoss.forward + bbox_iou(CIoU=True) + DFLoss and their autograd).  As torch ops on (B, K) tensors this
+// was ~60 forward and ~170 backward launches of a few microseconds each on 1 280 elements.  One thread per slot:
+//   ltrb_i = sum_j softmax(z_i)_j j;  pred = (ax - l, ay - t, ax + r, ay + b);  box = w (1 - CIoU(pred, target));
+//   dfl = w mean_i CE(z_i; lo_i, lo_i + 1 with weights (lo_i + 1 - d_i), (d_i - lo_i)),  d_i = clamp(target distance, 0, 14.99).
+// dCIoU/d(l,t,r,b) by forward-mode differentiation (a value with four tangents) of the very expression loss.ciou evaluates,
+// alpha held constant as there (torch.no_grad).
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+constexpr int REGM = 16;
+constexpr float CEPS = 1e-7f;
+
+struct D4 {
+  float v, d[4];
+};
+__device__ __forceinline__ D4 dc(float c) { return D4{c, {0.f, 0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ D4 operator+(D4 a, D4 b) { return D4{a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2], a.d[3] + b.d[3]}}; }
+__device__ __forceinline__ D4 operator-(D4 a, D4 b) { return D4{a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2], a.d[3] - b.d[3]}}; }
+__device__ __forceinline__ D4 operator*(D4 a, D4 b) {
+  return D4{a.v * b.v, {a.d[0] * b.v + a.v * b.d[0], a.d[1] * b.v + a.v * b.d[1], a.d[2] * b.v + a.v * b.d[2], a.d[3] * b.v + a.v * b.d[3]}};
+}
+__device__ __forceinline__ D4 operator/(D4 a, D4 b) {
+  const float q = a.v / b.v, r = 1.0f / b.v;
+  return D4{q, {(a.d[0] - q * b.d[0]) * r, (a.d[1] - q * b.d[1]) * r, (a.d[2] - q * b.d[2]) * r, (a.d[3] - q * b.d[3]) * r}};
+}
+__device__ __forceinline__ D4 dscale(D4 a, float c) { return D4{a.v * c, {a.d[0] * c, a.d[1] * c, a.d[2] * c, a.d[3] * c}}; }
+__device__ __forceinline__ D4 davg(D4 a, D4 b) { return dscale(a + b, 0.5f); }
+// torch.minimum / maximum: the gradient goes to the selected operand, half to each on a tie
+__device__ __forceinline__ D4 dmin(D4 a, D4 b) { return a.v < b.v ? a : (b.v < a.v ? b : davg(a, b)); }
+__device__ __forceinline__ D4 dmax(D4 a, D4 b) { return a.v > b.v ? a : (b.v > a.v ? b : davg(a, b)); }
+__device__ __forceinline__ D4 dclamp0(D4 a) { return a.v >= 0.f ? a : dc(0.f); }       // clamp_min(0): gradient where x >= 0
+__device__ __forceinline__ D4 datan(D4 a) {
+  const float r = 1.0f / (1.0f + a.v * a.v);
+  return D4{atanf(a.v), {a.d[0] * r, a.d[1] * r, a.d[2] * r, a.d[3] * r}};
+}
+
+__device__ __forceinline__ D4 ciou_d4(D4 ax1, D4 ay1, D4 ax2, D4 ay2, float bx1, float by1, float bx2, float by2) {
+  const D4 aw = ax2 - ax1, ah = ay2 - ay1 + dc(CEPS);
+  const float bw = bx2 - bx1, bh = by2 - by1 + CEPS;
+  const D4 iw = dclamp0(dmin(ax2, dc(bx2)) - dmax(ax1, dc(bx1)));
+  const D4 ih = dclamp0(dmin(ay2, dc(by2)) - dmax(ay1, dc(by1)));
+  const D4 inter = iw * ih;
+  const D4 iou = inter / (aw * ah + dc(bw * bh) - inter + dc(CEPS));
+  const D4 cw = dmax(ax2, dc(bx2)) - dmin(ax1, dc(bx1));
+  const D4 ch = dmax(ay2, dc(by2)) - dmin(ay1, dc(by1));
+  const D4 diag2 = cw * cw + ch * ch + dc(CEPS);
+  const D4 ex = dc(bx1 + bx2) - ax1 - ax2, ey = dc(by1 + by2) - ay1 - ay2;
+  const D4 centre2 = dscale(ex * ex + ey * ey, 0.25f);
+  const D4 da = dc(atanf(bw / bh)) - datan(aw / ah);
+  const D4 v = dscale(da * da, (float)(4.0 / (3.14159265358979323846 * 3.14159265358979323846)));
+  const float alpha = v.v / (v.v - iou.v + (1.0f + CEPS));
+  return iou - (centre2 / diag2 + dscale(v, alpha));
+}
+
+__global__ __launch_bounds__(64) void box_loss_kernel(const float* logits, const float* anchors, const float* targets, const float* weights,
+                                                      long n, float* box_term, float* dfl_term, float* d_box, float* d_dfl) {
+  const long s = (long)blockIdx.x * 64 + threadIdx.x;
+  if (s >= n) return;
+  const float w = weights[s];
+  float* const gb = d_box + s * 4 * REGM;
+  float* const gd = d_dfl + s * 4 * REGM;
+  if (!(w != 0.f)) {
+    for (int j = 0; j < 4 * REGM; ++j) { gb[j] = 0.f; gd[j] = 0.f; }
+    box_term[s] = 0.f;
+    dfl_term[s] = 0.f;
+    return;
+  }
+  const float ax = anchors[s * 2], ay = anchors[s * 2 + 1];
+  const float tx1 = targets[s * 4], ty1 = targets[s * 4 + 1], tx2 = targets[s * 4 + 2], ty2 = targets[s * 4 + 3];
+  const float tdist[4] = {ax - tx1, ay - ty1, tx2 - ax, ty2 - ay};
+  float p[4][REGM], E[4], ce[4], wl[4];
+  int lo[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float z[REGM];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) { z[j] = logits[(s * 4 + i) * REGM + j]; m = fmaxf(m, z[j]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) { p[i][j] = expf(z[j] - m); sum += p[i][j]; }
+    const float inv = 1.0f / sum, lse = m + logf(sum);
+    float e = 0.f;
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) { p[i][j] *= inv; e += p[i][j] * (float)j; }
+    E[i] = e;
+    const float dist = fminf(fmaxf(tdist[i], 0.f), (float)(REGM - 1) - 0.01f);
+    lo[i] = (int)dist;
+    wl[i] = (float)(lo[i] + 1) - dist;
+    float zlo = 0.f, zhi = 0.f;
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) { zlo = j == lo[i] ? z[j] : zlo; zhi = j == lo[i] + 1 ? z[j] : zhi; }
+    ce[i] = (lse - zlo) * wl[i] + (lse - zhi) * (dist - (float)lo[i]);
+  }
+  const D4 x1 = D4{ax - E[0], {-1.f, 0.f, 0.f, 0.f}}, y1 = D4{ay - E[1], {0.f, -1.f, 0.f, 0.f}};
+  const D4 x2 = D4{ax + E[2], {0.f, 0.f, 1.f, 0.f}}, y2 = D4{ay + E[3], {0.f, 0.f, 0.f, 1.f}};
+  const D4 c = ciou_d4(x1, y1, x2, y2, tx1, ty1, tx2, ty2);
+  box_term[s] = (1.0f - c.v) * w;
+  dfl_term[s] = ((ce[0] + ce[1] + ce[2] + ce[3]) * 0.25f) * w;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float gbox = -c.d[i] * w;
+    const float wh = 1.0f - wl[i];
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) {
+      gb[i * REGM + j] = gbox * p[i][j] * ((float)j - E[i]);
+      gd[i * REGM + j] = 0.25f * w * (p[i][j] - (j == lo[i] ? wl[i] : 0.f) - (j == lo[i] + 1 ? wh : 0.f));
+    }
+  }
+}
+
+// Boxes and class scores of ALL anchors for the assignment (no gradient): rows of the raw head map (rw = 64 + nc + nm floats,
+// 4-byte aligned rows) -> xyxy in pixels ((anchor -/+ expectation) * stride) and sigmoid(class logits).  64 rows per block
+// come in through LDS with coalesced loads (row pitch rw + 1 floats when rw is even: conflict-free column walks);
+// thread (row, side) owns 16 logits.
+__global__ __launch_bounds__(256) void dfl_decode_kernel(const float* raw, long rows, int A, int rw, int nc, const float* anchors,
+                                                         const float* strides, float* boxes, float* scores) {
+  extern __shared__ float tile[];
+  const int pitch = rw | 1;
+  const long r0 = (long)blockIdx.x * 64;
+  const int nr = rows - r0 >= 64 ? 64 : (int)(rows - r0);
+  const float* const src = raw + r0 * rw;
+  for (int i = threadIdx.x; i < nr * rw; i += 256) {
+    const int r = i / rw, c = i - r * rw;
+    tile[r * pitch + c] = src[i];
+  }
+  __syncthreads();
+  const int r = threadIdx.x >> 2, side = threadIdx.x & 3;
+  if (r < nr) {
+    const float* z = tile + r * pitch + side * REGM;
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) m = fmaxf(m, z[j]);
+    float t[REGM], sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) {
+      t[j] = expf(z[j] - m);
+      sum += t[j];
+    }
+    // softmax, then the expectation, as `(softmax * bins).sum()`: every p_j = t_j / sum is rounded before its product
+    const float inv = 1.0f / sum;
+    float ex = 0.f;
+#pragma unroll
+    for (int j = 0; j < REGM; ++j) ex += (t[j] * inv) * (float)j;
+    const long row = r0 + r;
+    const int a = (int)(row % A);
+    const float anc = anchors[a * 2 + (side & 1)];
+    const float v = side < 2 ? anc - ex : anc + ex;
+    boxes[row * 4 + side] = v * strides[a];
+  }
+  for (int i = threadIdx.x; i < nr * nc; i += 256) {
+    const int rr = i / nc, c = i - rr * nc;
+    scores[(r0 + rr) * nc + c] = sigmoid_exact(tile[rr * pitch + 4 * REGM + c]);
+  }
+}
+}  // namespace
+
+int launch_box_loss(const float* logits, const float* anchors, const float* targets, const float* weights, long n, float* box_term,
+                    float* dfl_term, float* d_box, float* d_dfl, hipStream_t s) {
+  if (!logits || !anchors || !targets || !weights || !box_term || !dfl_term || !d_box || !d_dfl || n < 1) return -1;
+  hipLaunchKernelGGL(box_loss_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, logits, anchors, targets, weights, n, box_term,
+                     dfl_term, d_box, d_dfl);
+  return (int)hipGetLastError();
+}
+
+int launch_dfl_decode(const float* raw, long rows, int A, int rw, int nc, const float* anchors, const float* strides, float* boxes,
+                      float* scores, hipStream_t s) {
+  if (!raw || !anchors || !strides || !boxes || !scores || rows < 1 || A < 1 || nc < 1 || rw < 4 * REGM + nc) return -1;
+  const size_t lds = (size_t)64 * (rw | 1) * sizeof(float);
+  if (lds > 64 * 1024) return -1;
+  hipLaunchKernelGGL(dfl_decode_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(256), lds, s, raw, rows, A, rw, nc, anchors, strides,
+                     boxes, scores);
+  return (int)hipGetLastError();
+}
+
 int launch_mask_loss(const float* coef, const void* protos, int protos_f16, const int* masks, const int* inst, const float* boxes,
                      const float* w, int B, int K, int mh, int mw, float* slot_sum, float* d_coef, float* d_protos, hipStream_t s) {
   if (!coef || !protos || !masks || !inst || !boxes || !w || !slot_sum || !d_coef || !d_protos) return -1;

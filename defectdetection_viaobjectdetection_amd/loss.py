@@ -97,7 +97,7 @@ def _consts(imgsz: Tuple[int, int], mh: int, mw: int, dev, gains: Tuple[float, f
     c = _CONST_CACHE.get(key)
     if c is None:
         anchors, strides = anchor_grid(imgsz, dev)
-        c = dict(anchors=anchors, strides=strides, bins=torch.arange(REG_MAX, device=dev, dtype=torch.float32),
+        c = dict(anchors=anchors, strides=strides, anchors_px=anchors * strides, strides_flat=strides.reshape(-1).contiguous(), bins=torch.arange(REG_MAX, device=dev, dtype=torch.float32),
                  wh=torch.tensor([imgsz[1], imgsz[0], imgsz[1], imgsz[0]], device=dev, dtype=torch.float32),
                  mwh=torch.tensor([mw, mh, mw, mh], device=dev, dtype=torch.float32),
                  cols=torch.arange(mw, device=dev, dtype=torch.float32).repeat(mh)[None, None, :],
@@ -137,9 +137,53 @@ def segmentation_loss(raw: torch.Tensor, protos: torch.Tensor, batch: Dict[str, 
     return loss_core(raw, protos, gt_cls, gt_boxes, gt_valid, batch["masks"].to(raw.device), nc, imgsz, (box_gain, cls_gain, dfl_gain))
 
 
-def _mask_kernel_enabled() -> bool:
+def _loss_kernels_enabled() -> bool:
+    """The HIP forms of the loss terms (device tensors only); M355_NO_LOSS_KERNELS=1 keeps the torch-op forms for A/B runs."""
     import os
-    return os.environ.get("M355_NO_MASK_KERNEL") != "1"
+    return os.environ.get("M355_NO_LOSS_KERNELS") != "1"
+
+
+def _stream():
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _decode_all(raw: torch.Tensor, anchors: torch.Tensor, strides_flat: torch.Tensor, nc: int):
+    """raw (B,A,64+nc+nm) fp32 -> xyxy boxes in pixels (B,A,4) and sigmoid class scores (B,A,nc) of every anchor."""
+    from ._capi import check, lib
+    B, A, rw = raw.shape
+    raw = raw.float().contiguous()
+    boxes = torch.empty((B, A, 4), dtype=torch.float32, device=raw.device)
+    scores = torch.empty((B, A, nc), dtype=torch.float32, device=raw.device)
+    check(lib.m355_dfl_decode_launch(raw.data_ptr(), B * A, A, rw, nc, anchors.data_ptr(), strides_flat.data_ptr(), boxes.data_ptr(),
+                                     scores.data_ptr(), _stream()))
+    return boxes, scores
+
+
+class _BoxTerm(torch.autograd.Function):
+    """(sum_s w_s (1 - CIoU_s), sum_s w_s DFL_s) over the foreground slots with d / d logits from the same device pass
+    (``m355_box_loss_launch``).  logits (B,K,4,16); anchors (B,K,2) and targets (B,K,4) in grid units; w (B,K)."""
+
+    @staticmethod
+    def forward(ctx, logits, anchors, targets, w):
+        from ._capi import check, lib
+        n = w.numel()
+        lg = logits.detach().float().contiguous()
+        an, tg, wc = anchors.float().contiguous(), targets.float().contiguous(), w.float().contiguous()
+        terms = torch.empty((2, n), dtype=torch.float32, device=lg.device)
+        grads = torch.empty((2, n, 4 * REG_MAX), dtype=torch.float32, device=lg.device)
+        check(lib.m355_box_loss_launch(lg.data_ptr(), an.data_ptr(), tg.data_ptr(), wc.data_ptr(), n, terms[0].data_ptr(),
+                                       terms[1].data_ptr(), grads[0].data_ptr(), grads[1].data_ptr(), _stream()))
+        ctx.save_for_backward(grads)
+        ctx.shape = logits.shape
+        sums = terms.sum(1)
+        return sums[0], sums[1]
+
+    @staticmethod
+    def backward(ctx, g_box, g_dfl):
+        (grads,) = ctx.saved_tensors
+        g = grads[0] * g_box + grads[1] * g_dfl
+        return g.view(ctx.shape), None, None, None
 
 
 class _MaskTerm(torch.autograd.Function):
@@ -150,7 +194,6 @@ class _MaskTerm(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, coef, protos, masks, inst, boxes, w):
-        import ctypes as C
         from ._capi import check, lib
         B, K, _ = coef.shape
         mh, mw = protos.shape[1:3]
@@ -163,8 +206,7 @@ class _MaskTerm(torch.autograd.Function):
         d_protos = torch.empty((B, mh, mw, NM), dtype=torch.float32, device=coef.device)
         check(lib.m355_mask_loss_launch(coef_c.data_ptr(), protos_c.data_ptr(), 1 if protos.dtype == torch.float16 else 0,
                                         masks_i.data_ptr(), inst_i.data_ptr(), boxes_c.data_ptr(), w_c.data_ptr(), B, K, mh, mw,
-                                        slot_sum.data_ptr(), d_coef.data_ptr(), d_protos.data_ptr(),
-                                        C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+                                        slot_sum.data_ptr(), d_coef.data_ptr(), d_protos.data_ptr(), _stream()))
         ctx.save_for_backward(d_coef, d_protos)
         ctx.protos_dtype = protos.dtype
         return (slot_sum * w_c).sum() / float(mh * mw)
@@ -190,11 +232,15 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
     # the <= 10 G foreground slots per image: every other anchor has weight zero, and carrying the (B, A, 4, 16) logits
     # through softmax, log-softmax, two gathers and their backward passes cost ~2 ms of a 5.3 ms loss for 0.2 % of the rows.
     # expectation over the 16 bins as multiply + reduce: `softmax @ bins` runs as a (B*A*4) x 16 rocBLAS gemv, 1.4 ms
+    use_kernels = raw.is_cuda and _loss_kernels_enabled()
     with torch.no_grad():
-        ltrb = (logits_box.view(B, A, 4, REG_MAX).softmax(3) * bins).sum(3)
-        pred_boxes = torch.cat((anchors - ltrb[..., :2], anchors + ltrb[..., 2:]), -1)   # grid units
-    t_boxes, t_scores, fg, gt_idx = assign_targets(logits_cls.detach().sigmoid(), pred_boxes * strides,
-                                                   anchors * strides, gt_cls, gt_boxes, gt_valid)
+        if use_kernels:                                    # one pass over the raw rows (csrc/loss_kernels.hip)
+            boxes_px, scores = _decode_all(raw.detach(), anchors, k["strides_flat"], nc)
+        else:
+            ltrb = (logits_box.view(B, A, 4, REG_MAX).softmax(3) * bins).sum(3)
+            boxes_px = torch.cat((anchors - ltrb[..., :2], anchors + ltrb[..., 2:]), -1) * strides       # pixels
+            scores = logits_cls.detach().sigmoid()
+    t_boxes, t_scores, fg, gt_idx = assign_targets(scores, boxes_px, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
     # Everything below runs over ALL anchors / a fixed number of slots per image with zero weights for the background,
     # so the step has no data-dependent shapes and no host synchronisation after the one that sized the GT padding.
     denom = t_scores.sum().clamp_min(1.0)
@@ -212,15 +258,19 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
         anc = anchors[ai]                                                            # (B,K,2) grid units
         tb = (t_boxes / strides).gather(1, ai[..., None].expand(B, K, 4))
         lb = logits_box.gather(1, ai[..., None].expand(B, K, 4 * REG_MAX)).view(B, K, 4, REG_MAX)
-        ltrb_s = (lb.softmax(3) * bins).sum(3)
-        pred_s = torch.cat((anc - ltrb_s[..., :2], anc + ltrb_s[..., 2:]), -1)
-        loss_box = ((1.0 - ciou(pred_s, tb)) * ws).sum() / denom
-        dist = torch.cat((anc - tb[..., :2], tb[..., 2:] - anc), -1).clamp(0, REG_MAX - 1 - 0.01)       # (B,K,4)
-        lo = dist.long()
-        logp = lb.log_softmax(3)
-        ce_lo = -logp.gather(3, lo[..., None]).squeeze(3)
-        ce_hi = -logp.gather(3, lo[..., None] + 1).squeeze(3)
-        loss_dfl = (((ce_lo * (lo + 1 - dist) + ce_hi * (dist - lo)).mean(2)) * ws).sum() / denom
+        if use_kernels:                                    # value and gradient of both terms in one pass, one thread per slot
+            box_sum, dfl_sum = _BoxTerm.apply(lb, anc, tb.detach(), ws.detach())
+            loss_box, loss_dfl = box_sum / denom, dfl_sum / denom
+        else:
+            ltrb_s = (lb.softmax(3) * bins).sum(3)
+            pred_s = torch.cat((anc - ltrb_s[..., :2], anc + ltrb_s[..., 2:]), -1)
+            loss_box = ((1.0 - ciou(pred_s, tb)) * ws).sum() / denom
+            dist = torch.cat((anc - tb[..., :2], tb[..., 2:] - anc), -1).clamp(0, REG_MAX - 1 - 0.01)       # (B,K,4)
+            lo = dist.long()
+            logp = lb.log_softmax(3)
+            ce_lo = -logp.gather(3, lo[..., None]).squeeze(3)
+            ce_hi = -logp.gather(3, lo[..., None] + 1).squeeze(3)
+            loss_dfl = (((ce_lo * (lo + 1 - dist) + ce_hi * (dist - lo)).mean(2)) * ws).sum() / denom
         # masks: BCE(coef . proto, gt mask of the assigned instance) inside the target box, mean over the map, divided by
         # the normalised box area; one batched GEMM (B,K,32) x (B,32,mh*mw).
         nb = t_boxes.gather(1, ai[..., None].expand(B, K, 4)) / k["wh"]
@@ -229,7 +279,7 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
         ck = coefs.gather(1, ai[..., None].expand(B, K, NM))
         inst = gt_idx.gather(1, ai) + 1
         nfg = fg.sum().clamp_min(1)
-        if raw.is_cuda and _mask_kernel_enabled():
+        if use_kernels:
             # one HIP pass over the boxes' pixels gives the term and both gradients (csrc/loss_kernels.hip)
             loss_seg = _MaskTerm.apply(ck, protos, masks, inst, mbox.detach(), (valid / (area * nfg)).detach())
         else:
@@ -268,7 +318,7 @@ class GraphedSegLoss:
         self._states: Dict = {}
 
     def _eager(self, raw, protos, gt, masks, scale):
-        r = raw.detach().clone().requires_grad_(True)
+        r = raw.detach().requires_grad_(True)             # shares the engine's buffer: the loss never writes to its inputs
         # on the device the prototypes stay fp16 (the engine's own buffer): the mask kernel reads them as they are and the
         # gradient comes back in the dtype TrainEngine.backward stores anyway
         p = (protos.detach() if protos.is_cuda else protos.detach().float()).requires_grad_(True)

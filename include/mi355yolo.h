@@ -264,6 +264,19 @@ int m355_mask_loss_launch(const float* coef, const void* protos, int32_t protos_
                           const float* boxes, const float* weights, int32_t B, int32_t K, int32_t mh, int32_t mw, float* slot_sum,
                           float* d_coef, float* d_protos, void* stream);
 
+/* Box (CIoU) and DFL terms of the loss on n foreground slots with their gradients w.r.t. the slot's 4 x 16 distribution logits,
+ * one pass (replaces BboxLoss.forward / bbox_iou(CIoU=True) / DFLoss and their autograd, yolo_seg_train.py:12).  logits (n,4,16);
+ * anchors (n,2) cell centres and targets (n,4) xyxy, both in grid units; weights (n), 0 = skip the slot (outputs 0).
+ * box_term[s] = w (1 - CIoU(anchor -/+ E[softmax], target)), dfl_term[s] = w mean over the 4 sides of the two-bin cross entropy
+ * at clamp(target distance, 0, 14.99); d_box / d_dfl (n,64) = d box_term / d logits, d dfl_term / d logits. */
+int m355_box_loss_launch(const float* logits, const float* anchors, const float* targets, const float* weights, int64_t n,
+                         float* box_term, float* dfl_term, float* d_box, float* d_dfl, void* stream);
+/* Boxes and class scores of all anchors for the target assignment (no gradient): raw (rows, rw) head rows [64 DFL logits | nc class
+ * logits | ...], row r belongs to anchor r % A -> boxes (rows,4) xyxy pixels = (anchor -/+ E[softmax over 16 bins]) * stride,
+ * scores (rows,nc) = sigmoid.  anchors (A,2) grid units, strides (A). */
+int m355_dfl_decode_launch(const float* raw, int64_t rows, int32_t A, int32_t rw, int32_t nc, const float* anchors, const float* strides,
+                           float* boxes, float* scores, void* stream);
+
 /* Optimizer step over a flat fp32 parameter buffer (replaces torch.optim.AdamW / SGD + ModelEMA.update reached from
  * /root/reference/BscanBased/yolo_seg_train.py:12).  group[i]: 0 decayed weights, 1 norm weights, 2 biases (lr_bias).
  * grad_mul = clip_coef / loss_scale.  ema may be NULL.  step counts from 1 (Adam bias correction). */
