@@ -173,7 +173,8 @@ int launch_upsample2x_bwd(const half_t* g, long g_bs, int ldg, half_t* d, long d
 int launch_u8_to_f16x8(const unsigned char* src, half_t* dst, long npx, hipStream_t s);
 // mask term of the segmentation loss + its gradients in one pass (loss_kernels.hip)
 int launch_mask_loss(const float* coef, const void* protos, int protos_f16, const int* masks, const int* inst, const float* boxes,
-                     const float* w, int B, int K, int mh, int mw, float* slot_sum, float* d_coef, float* d_protos, hipStream_t s);
+                     const float* w, int B, int K, int mh, int mw, float* slot_sum, float* d_coef, void* d_protos, int d_protos_f16,
+                     const float* gscale, hipStream_t s);
 int launch_box_loss(const float* logits, const float* anchors, const float* targets, const float* weights, long n, float* box_term,
                     float* dfl_term, float* d_box, float* d_dfl, hipStream_t s);
 int launch_dfl_decode(const float* raw, long rows, int A, int rw, int nc, const float* anchors, const float* strides, float* boxes,

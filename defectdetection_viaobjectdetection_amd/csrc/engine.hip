@@ -1829,9 +1829,9 @@ int m355_u8_to_f16x8_launch(const uint8_t* src, void* dst, int64_t npx, void* st
 
 int m355_mask_loss_launch(const float* coef, const void* protos, int32_t protos_f16, const int32_t* masks, const int32_t* inst,
                           const float* boxes, const float* weights, int32_t B, int32_t K, int32_t mh, int32_t mw, float* slot_sum,
-                          float* d_coef, float* d_protos, void* stream) {
+                          float* d_coef, void* d_protos, int32_t d_protos_f16, const float* gscale, void* stream) {
   const int rc = launch_mask_loss(coef, protos, protos_f16, masks, inst, boxes, weights, B, K, mh, mw, slot_sum, d_coef, d_protos,
-                                  (hipStream_t)stream);
+                                  d_protos_f16, gscale, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "mask-loss launch failed: " + std::to_string(rc));
 }
 

@@ -11,8 +11,10 @@
 // loss or gradient, and the gradient needs nothing but the forward values, so forward and backward are ONE pass here:
 //   * mask_loss_slot_kernel, one block per (image, slot): walks the box, accumulates sum[b,k] and d L / d coef[b,k,:] in
 //     registers, block tree reduction in a fixed order (bitwise reproducible; no float atomics);
-//   * mask_loss_proto_kernel, one thread per prototype pixel: d L / d proto[b,p,:] over the slots whose box holds the pixel.
-// HBM traffic is the prototype map once per kernel plus the dense gradient map (fp32): ~0.3 GB at batch 64.
+//   * mask_loss_proto_kernel, one thread per prototype pixel: d L / d proto[b,p,:] over the slots whose box holds the pixel,
+//     times the incoming gradient of L (a device scalar), stored in the prototypes' own dtype -- launched from the autograd
+//     backward, so the dense map is written once, already scaled (a stored fp32 map, `* g` and `.half()` were 3 passes).
+// HBM traffic is the prototype map once per kernel plus the gradient map once: ~0.2 GB at batch 64.
 #include "common.h"
 
 namespace m355 {
@@ -119,10 +121,10 @@ __global__ __launch_bounds__(256) void mask_loss_slot_kernel(const float* coef, 
   if (threadIdx.x == 0) slot_sum[sk] = red[NMK];
 }
 
-template <bool F16>
+template <bool F16, bool OUT16>
 __global__ __launch_bounds__(256) void mask_loss_proto_kernel(const float* coef, const void* protos, const int* masks, const int* inst,
                                                               const float* boxes, const float* w, int K, int mh, int mw, float inv_hw,
-                                                              float* d_protos) {
+                                                              const float* gscale, void* d_protos) {
   const int b = blockIdx.y;
   const int hw = mh * mw;
   const int p0 = blockIdx.x * 256;
@@ -163,9 +165,21 @@ __global__ __launch_bounds__(256) void mask_loss_proto_kernel(const float* coef,
     }
   }
   if (live) {
-    float4v* o = (float4v*)(d_protos + gp * NMK);
+    const float gs = gscale ? *gscale : 1.0f;             // the incoming gradient of L (a device scalar): applied here, not in a pass of its own
+    if (OUT16) {
+      half8* o = (half8*)((half_t*)d_protos + gp * NMK);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) o[u] = float4v{dp[u * 4], dp[u * 4 + 1], dp[u * 4 + 2], dp[u * 4 + 3]};
+      for (int u = 0; u < 4; ++u) {
+        half8 h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = m355_to_half(dp[u * 8 + j] * gs);
+        o[u] = h;
+      }
+    } else {
+      float4v* o = (float4v*)((float*)d_protos + gp * NMK);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) o[u] = float4v{dp[u * 4] * gs, dp[u * 4 + 1] * gs, dp[u * 4 + 2] * gs, dp[u * 4 + 3] * gs};
+    }
   }
 }
 }  // namespace
@@ -347,21 +361,28 @@ int launch_dfl_decode(const float* raw, long rows, int A, int rw, int nc, const 
 }
 
 int launch_mask_loss(const float* coef, const void* protos, int protos_f16, const int* masks, const int* inst, const float* boxes,
-                     const float* w, int B, int K, int mh, int mw, float* slot_sum, float* d_coef, float* d_protos, hipStream_t s) {
-  if (!coef || !protos || !masks || !inst || !boxes || !w || !slot_sum || !d_coef || !d_protos) return -1;
+                     const float* w, int B, int K, int mh, int mw, float* slot_sum, float* d_coef, void* d_protos, int d_protos_f16,
+                     const float* gscale, hipStream_t s) {
+  if (!coef || !protos || !masks || !inst || !boxes || !w || (!slot_sum != !d_coef) || (!slot_sum && !d_protos)) return -1;
   if (B < 1 || K < 1 || mh < 1 || mw < 1 || K > 65535 || B > 65535 || (long)mh * mw > (1L << 30)) return -1;
   const float inv_hw = 1.0f / (float)((long)mh * mw);
   const dim3 gs(K, B), gp((mh * mw + 255) / 256, B);
-  if (protos_f16) {
-    hipLaunchKernelGGL(mask_loss_slot_kernel<true>, gs, dim3(256), 0, s, coef, protos, masks, inst, boxes, w, K, mh, mw, inv_hw, slot_sum,
-                       d_coef);
-    hipLaunchKernelGGL(mask_loss_proto_kernel<true>, gp, dim3(256), 0, s, coef, protos, masks, inst, boxes, w, K, mh, mw, inv_hw,
-                       d_protos);
-  } else {
-    hipLaunchKernelGGL(mask_loss_slot_kernel<false>, gs, dim3(256), 0, s, coef, protos, masks, inst, boxes, w, K, mh, mw, inv_hw, slot_sum,
-                       d_coef);
-    hipLaunchKernelGGL(mask_loss_proto_kernel<false>, gp, dim3(256), 0, s, coef, protos, masks, inst, boxes, w, K, mh, mw, inv_hw,
-                       d_protos);
+  if (slot_sum) {
+    if (protos_f16)
+      hipLaunchKernelGGL(mask_loss_slot_kernel<true>, gs, dim3(256), 0, s, coef, protos, masks, inst, boxes, w, K, mh, mw, inv_hw, slot_sum,
+                         d_coef);
+    else
+      hipLaunchKernelGGL(mask_loss_slot_kernel<false>, gs, dim3(256), 0, s, coef, protos, masks, inst, boxes, w, K, mh, mw, inv_hw, slot_sum,
+                         d_coef);
+  }
+  if (d_protos) {
+#define M355_PROTO_LAUNCH(F, O) \
+  hipLaunchKernelGGL((mask_loss_proto_kernel<F, O>), gp, dim3(256), 0, s, coef, protos, masks, inst, boxes, w, K, mh, mw, inv_hw, gscale, d_protos)
+    if (protos_f16 && d_protos_f16) M355_PROTO_LAUNCH(true, true);
+    else if (protos_f16) M355_PROTO_LAUNCH(true, false);
+    else if (d_protos_f16) M355_PROTO_LAUNCH(false, true);
+    else M355_PROTO_LAUNCH(false, false);
+#undef M355_PROTO_LAUNCH
   }
   return (int)hipGetLastError();
 }

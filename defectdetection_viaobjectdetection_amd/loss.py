@@ -187,10 +187,10 @@ class _BoxTerm(torch.autograd.Function):
 
 
 class _MaskTerm(torch.autograd.Function):
-    """sum_{b,k} w[b,k] * mean_p(BCE(coef[b,k] . proto[b,p], mask[b,p] == inst[b,k]) inside box[b,k]) with both gradients from
-    ONE device pass (``m355_mask_loss_launch``): the gradients need only forward values, so they are computed with the value
-    and scaled by the incoming gradient in ``backward``.  coef (B,K,32) fp32; protos (B,mh,mw,32) fp16 or fp32; masks
-    (B,mh,mw) overlap-encoded; inst (B,K); boxes (B,K,4) prototype px; w (B,K), 0 = skip the slot."""
+    """sum_{b,k} w[b,k] * mean_p(BCE(coef[b,k] . proto[b,p], mask[b,p] == inst[b,k]) inside box[b,k]) (``m355_mask_loss_launch``).
+    The gradients need only forward values: d / d coef comes out of the forward pass over the boxes with the value; the dense
+    d / d protos is produced in ``backward``, already scaled by the incoming gradient.  coef (B,K,32) fp32; protos
+    (B,mh,mw,32) fp16 or fp32; masks (B,mh,mw) overlap-encoded; inst (B,K); boxes (B,K,4) prototype px; w (B,K), 0 = skip."""
 
     @staticmethod
     def forward(ctx, coef, protos, masks, inst, boxes, w):
@@ -203,18 +203,28 @@ class _MaskTerm(torch.autograd.Function):
         boxes_c, w_c = boxes.float().contiguous(), w.float().contiguous()
         slot_sum = torch.empty((B, K), dtype=torch.float32, device=coef.device)
         d_coef = torch.empty((B, K, NM), dtype=torch.float32, device=coef.device)
-        d_protos = torch.empty((B, mh, mw, NM), dtype=torch.float32, device=coef.device)
-        check(lib.m355_mask_loss_launch(coef_c.data_ptr(), protos_c.data_ptr(), 1 if protos.dtype == torch.float16 else 0,
-                                        masks_i.data_ptr(), inst_i.data_ptr(), boxes_c.data_ptr(), w_c.data_ptr(), B, K, mh, mw,
-                                        slot_sum.data_ptr(), d_coef.data_ptr(), d_protos.data_ptr(), _stream()))
-        ctx.save_for_backward(d_coef, d_protos)
-        ctx.protos_dtype = protos.dtype
+        f16 = 1 if protos.dtype == torch.float16 else 0
+        check(lib.m355_mask_loss_launch(coef_c.data_ptr(), protos_c.data_ptr(), f16, masks_i.data_ptr(), inst_i.data_ptr(),
+                                        boxes_c.data_ptr(), w_c.data_ptr(), B, K, mh, mw, slot_sum.data_ptr(), d_coef.data_ptr(), None, 0,
+                                        None, _stream()))
+        ctx.save_for_backward(coef_c, protos_c, masks_i, inst_i, boxes_c, w_c, d_coef)
         return (slot_sum * w_c).sum() / float(mh * mw)
 
     @staticmethod
     def backward(ctx, g):
-        d_coef, d_protos = ctx.saved_tensors
-        return d_coef * g, (d_protos * g).to(ctx.protos_dtype), None, None, None, None
+        # the dense prototype gradient is produced here, already multiplied by the incoming gradient (read from the device by the
+        # kernel) and in the prototypes' dtype: one write of the map instead of fp32 store + multiply + cast
+        from ._capi import check, lib
+        coef_c, protos_c, masks_i, inst_i, boxes_c, w_c, d_coef = ctx.saved_tensors
+        B, K, _ = coef_c.shape
+        mh, mw = protos_c.shape[1:3]
+        f16 = 1 if protos_c.dtype == torch.float16 else 0
+        gs = g.detach().float().contiguous()
+        d_protos = torch.empty_like(protos_c)
+        check(lib.m355_mask_loss_launch(coef_c.data_ptr(), protos_c.data_ptr(), f16, masks_i.data_ptr(), inst_i.data_ptr(),
+                                        boxes_c.data_ptr(), w_c.data_ptr(), B, K, mh, mw, None, None, d_protos.data_ptr(), f16,
+                                        gs.data_ptr(), _stream()))
+        return d_coef * g, d_protos, None, None, None, None
 
 
 def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_boxes: torch.Tensor, gt_valid: torch.Tensor,

@@ -256,13 +256,15 @@ int m355_u8_to_f16x8_launch(const uint8_t* src, void* dst, int64_t npx, void* st
  * v8SegmentationLoss.single_mask_loss and its autograd, reached from /root/reference/BscanBased/yolo_seg_train.py:12).
  * For slot k of image b (a foreground anchor): pred[p] = coef[b,k,:] . protos[b,p,:] over 32 channels,
  * slot_sum[b,k] = sum over the pixels p with x1 <= col < x2, y1 <= row < y2 of BCEWithLogits(pred[p], masks[b,p] == inst[b,k]);
- * with L = (1 / (mh mw)) sum_{b,k} weights[b,k] slot_sum[b,k]:  d_coef = dL/dcoef (B,K,32), d_protos = dL/dprotos (B,mh,mw,32)
- * fp32, every element written.  protos (B,mh,mw,32) NHWC fp16 (protos_f16 = 1) or fp32; masks (B,mh,mw) int32
- * overlap-encoded; boxes (B,K,4) x1,y1,x2,y2 in prototype pixels; a slot with weight 0 is skipped (its outputs are 0).
- * No float atomics: bitwise reproducible. */
+ * with L = (1 / (mh mw)) sum_{b,k} weights[b,k] slot_sum[b,k]:  d_coef = dL/dcoef (B,K,32) fp32;  d_protos = g * dL/dprotos
+ * (B,mh,mw,32), fp32 or fp16 (d_protos_f16 = 1), every element written, g = *gscale (a DEVICE scalar: the gradient arriving at L
+ * in the caller's backward pass) or 1 when gscale is NULL.  slot_sum + d_coef and d_protos are two independent kernels: pass
+ * slot_sum = d_coef = NULL or d_protos = NULL to run only one of them (forward: value and d_coef; backward: d_protos).
+ * protos (B,mh,mw,32) NHWC fp16 (protos_f16 = 1) or fp32; masks (B,mh,mw) int32 overlap-encoded; boxes (B,K,4) x1,y1,x2,y2 in
+ * prototype pixels; a slot with weight 0 is skipped (its outputs are 0).  No float atomics: bitwise reproducible. */
 int m355_mask_loss_launch(const float* coef, const void* protos, int32_t protos_f16, const int32_t* masks, const int32_t* inst,
                           const float* boxes, const float* weights, int32_t B, int32_t K, int32_t mh, int32_t mw, float* slot_sum,
-                          float* d_coef, float* d_protos, void* stream);
+                          float* d_coef, void* d_protos, int32_t d_protos_f16, const float* gscale, void* stream);
 
 /* Box (CIoU) and DFL terms of the loss on n foreground slots with their gradients w.r.t. the slot's 4 x 16 distribution logits,
  * one pass (replaces BboxLoss.forward / bbox_iou(CIoU=True) / DFLoss and their autograd, yolo_seg_train.py:12).  logits (n,4,16);

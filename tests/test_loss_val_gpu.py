@@ -236,15 +236,23 @@ def test_mask_loss_abi_edge_cases(cuda_device):
         o_dc = torch.full((B, K, 32), float("nan"), device=cuda_device)
         o_dp = torch.full((B, mh, mw, 32), float("nan"), device=cuda_device)
         capi.check(capi.lib.m355_mask_loss_launch(dc.data_ptr(), dp.data_ptr(), f16, dm.data_ptr(), di.data_ptr(), db.data_ptr(),
-                                                  dw.data_ptr(), B, K, mh, mw, o_sum.data_ptr(), o_dc.data_ptr(), o_dp.data_ptr(), st))
+                                                  dw.data_ptr(), B, K, mh, mw, o_sum.data_ptr(), o_dc.data_ptr(), o_dp.data_ptr(), 0, None, st))
+        # the prototype gradient alone, scaled by a device scalar, stored as fp16
+        gsc = torch.tensor(48.0, device=cuda_device)
+        o_dp16 = torch.full((B, mh, mw, 32), float("nan"), dtype=torch.float16, device=cuda_device)
+        capi.check(capi.lib.m355_mask_loss_launch(dc.data_ptr(), dp.data_ptr(), f16, dm.data_ptr(), di.data_ptr(), db.data_ptr(),
+                                                  dw.data_ptr(), B, K, mh, mw, None, None, o_dp16.data_ptr(), 1, gsc.data_ptr(), st))
         torch.cuda.synchronize()
         want_sum = (ssum * (w != 0)).detach()
         np.testing.assert_allclose(o_sum.cpu().double().numpy(), want_sum.numpy(), rtol=1e-5, atol=1e-6)
         np.testing.assert_allclose(o_dc.cpu().double().numpy(), c64.grad.numpy(), rtol=1e-4, atol=1e-7)
         np.testing.assert_allclose(o_dp.cpu().double().numpy(), p64.grad.numpy(), rtol=1e-4, atol=1e-8)
+        assert torch.equal(o_dp16.cpu(), (o_dp * 48.0).half().cpu())
         assert float(o_sum[:, 3].abs().max()) == 0.0 and float(o_sum[:, 4].abs().max()) == 0.0      # empty / outside boxes
     assert capi.lib.m355_mask_loss_launch(dc.data_ptr(), dp.data_ptr(), 1, dm.data_ptr(), di.data_ptr(), db.data_ptr(), dw.data_ptr(),
-                                          B, 0, mh, mw, o_sum.data_ptr(), o_dc.data_ptr(), o_dp.data_ptr(), st) != 0
+                                          B, 0, mh, mw, o_sum.data_ptr(), o_dc.data_ptr(), o_dp.data_ptr(), 0, None, st) != 0
+    assert capi.lib.m355_mask_loss_launch(dc.data_ptr(), dp.data_ptr(), 1, dm.data_ptr(), di.data_ptr(), db.data_ptr(), dw.data_ptr(),
+                                          B, K, mh, mw, None, None, None, 0, None, st) != 0                 # nothing to compute
 
 
 def test_box_loss_abi_against_autograd(cuda_device):
