@@ -40,7 +40,7 @@ def run(hw, cin, cout, out_f32, ldy, label):
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 30 * 1e3
     mb = B * hw * hw * (cin * 2 + cout * (4 if out_f32 else 2)) / 1e6
-    print(f"{label:44s} {hw}^2 {cin}->{cout}: {us:7.1f} us  {mb:6.1f} MB  {mb / us / 1e3:5.2f} TB/s")
+    print(f"{label:44s} {hw}^2 {cin}->{cout}: {us:7.1f} us  {mb:6.1f} MB  {mb / us:5.2f} TB/s")
 
 
 for hw in (80, 40):
