@@ -51,7 +51,12 @@ __device__ __forceinline__ void fast_divmod(int n, int d, float inv_d, int& q, i
 }
 
 // MT/NT: 16x16 MFMA tiles per wave along channels / pixels.  WCH/WPX: waves along channels / pixels.
-template <int MT, int NT, int WCH, int WPX, int KS>
+// EPI selects the special epilogues that only one launch of the network uses, each in an instantiation of its own:
+//   0 plain (every other launch), 1 head output conv + box decode (a.dec_preds), 2 phase conv + proto.cv3 (a.phase && a.w2).
+// Compiled into the one 128x128 1x1 kernel, the decode epilogue's register peak made the allocator spill 5 VGPRs at the top of
+// EVERY 1x1 launch (24 B of scratch per lane, stored whether or not the epilogue ran: 8 MB of scratch writes per launch beside
+// 75 MB of tensors, PMC WRITE_SIZE) -- the dominant kernel family paid for an epilogue that is off by default.
+template <int MT, int NT, int WCH, int WPX, int KS, int EPI = 0>
 __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv_igemm_kernel(const ConvArgs a) {  // (threads, min waves per SIMD)
   constexpr int NW = WCH * WPX;       // waves per workgroup: 4, or 8 (half-size wave tiles: four waves per SIMD with two
                                       // workgroups per CU hide the ~100-cycle issue cost of each LDS-DMA piece)
@@ -101,8 +106,12 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
   const float inv_tch = 1.0f / (float)tiles_ch;
 
   const bool lin1 = KS == 1 && a.stride == 1 && a.pad == 0 && a.x_bstride == (long)HoWo * a.ldx;
-  long rowoff[A_IT];        // element offset of (b, hi0, wi0, 0) for each of this lane's pixel rows
-  long rowoff2[KS == 1 ? A_IT : 1];   // upsample read-through: element offset of (b, h >> 1, w >> 1, 0) in x2
+  // Offsets in units of 8 elements (16 bytes; every stride is a multiple of 8, checked by the launcher): 32-bit registers.  As
+  // 64-bit element offsets the two arrays cost 8 more VGPRs in the 128x128 1x1 kernel, which then spilled 5 registers to
+  // scratch -- 8 MB of scratch writes per launch on top of 75 MB of tensors (PMC WRITE_SIZE), 35 registers / 140 MB in the
+  // composed Proto kernel.
+  int rowoff[A_IT];         // (b, hi0, wi0, 0) for each of this lane's pixel rows (may be negative: padding)
+  int rowoff2[KS == 1 ? A_IT : 1];    // upsample read-through: (b, h >> 1, w >> 1, 0) in x2
   unsigned rowmask[A_IT];   // bit t: tap t is inside the image (and the row is < M)
   const half_t* wsrc[W_IT]; // this lane's weight rows (+ chunk column)
   int ld_tile = lb;         // loader cursor: tile, K step within the tile, global stage count
@@ -122,10 +131,10 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
         int b2, pix2, ho2, wo2;
         fast_divmod(mm, HoWo, inv_howo, b2, pix2);
         fast_divmod(pix2, a.Wo, inv_wo, ho2, wo2);
-        rowoff2[KS == 1 ? i : 0] = (long)b2 * a.x2_bstride + ((long)(ho2 >> 1) * (a.Wo >> 1) + (wo2 >> 1)) * a.ldx2;
+        rowoff2[KS == 1 ? i : 0] = (int)(((long)b2 * a.x2_bstride + ((long)(ho2 >> 1) * (a.Wo >> 1) + (wo2 >> 1)) * a.ldx2) >> 3);
       }
       if (KS == 1 && lin1) {   // 1x1 / stride 1 over contiguous images: the pixel index is the row index
-        rowoff[i] = (long)mm * a.ldx;
+        rowoff[i] = (int)(((long)mm * a.ldx) >> 3);
         rowmask[i] = mv ? 1u : 0u;
         continue;
       }
@@ -172,7 +181,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
         }
       }
       if (!mv) mk = 0;
-      rowoff[i] = off;
+      rowoff[i] = (int)(off >> 3);          // arithmetic shift: off is a multiple of 8, negative for the top / left padding
       rowmask[i] = mk;
     }
     // weights: LDS row R (tile-local) holds the weight row of the channel the MFMA row maps to, so that
@@ -218,8 +227,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
 #pragma clang loop unroll(full)
     for (int i = 0; i < A_IT; ++i) {
       const bool ok = (rowmask[i] >> tap) & 1u;
-      const half_t* src = ok ? (a.x + rowoff[i] + tapoff) : a.zero;
-      if (KS == 1 && a.csplit > 0 && ok && kq < a.csplit) src = a.x2 + rowoff2[KS == 1 ? i : 0] + kq;
+      const half_t* src = ok ? (a.x + ((long)rowoff[i] << 3) + tapoff) : a.zero;
+      if (KS == 1 && a.csplit > 0 && ok && kq < a.csplit) src = a.x2 + ((long)rowoff2[KS == 1 ? i : 0] << 3) + kq;
       if (!skip_a) glds16(src, ab + (wave * (BPX / NW) + i * 8) * ROWB);
     }
     ++ld_g;
@@ -427,7 +436,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
         }
       }
     }
-    if (KS == 1 && MT == 4 && NT == 4 && WCH == 2 && a.dec_preds) {
+    if (EPI == 1 && KS == 1 && MT == 4 && NT == 4 && WCH == 2 && a.dec_preds) {
       // Head output conv + decode (the launcher checked: fp32 out, one channel tile, (wi + wo) * 64 floats fit the stages).
       // Two passes of 64 pixels = the 64-anchor blocks of head_decode_kernel, same arithmetic in the same order: the raw
       // row of a pixel goes to LDS instead of (or besides) HBM, four threads per anchor decode it, the prediction rows
@@ -507,7 +516,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       __syncthreads();                              // (persistent mode: the stages are reused by the next tile)
       if (!a.dec_keep_raw) continue;
     }
-    if (KS == 2 && MT == 4 && NT == 4 && WCH == 2 && a.phase && a.w2) {
+    if (EPI == 2 && KS == 2 && MT == 4 && NT == 4 && WCH == 2) {   // (the launcher checked a.phase && a.w2)
       // Phase conv + proto.cv3 in one epilogue.  The 128 ch x 128 px tile Z = SiLU(phase conv) goes to LDS as fp16
       // [pixel][128 ch] (16-byte chunk c of pixel p in slot c ^ (p & 15): conflict-free for the writes below and for the
       // B-fragment reads), the 32 x 128 weights of the 1x1 conv likewise [row][128] with the usual row permutation;
@@ -574,15 +583,15 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
           for (int nt2 = 0; nt2 < 2; ++nt2)
             acc2[mt2][nt2] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2[mt2], b2[nt2], acc2[mt2][nt2], 0, 0, 0);
       }
+      // Store.  Lane (g, l15) holds channels 8g..8g+7 of pixel l15: stored from there, the four 16-byte pieces of a pixel's
+      // 64-byte row leave from lanes 16 apart and reach memory as four separate partial writes (PMC: 189 MB written per launch
+      // for 52 MB of prototypes).  The rows go through the wave's own Z rows in LDS (its MFMAs above were their only readers)
+      // and come back as lane = 4 * pixel + piece: four adjacent lanes = one whole row per request.
       const float4v c0 = *(const float4v*)(a.bias2 + g * 8), c1 = *(const float4v*)(a.bias2 + g * 8 + 4);
+      char* const ob = zb + wave * 32 * 256;             // 32 px x 64 B, piece c of pixel pl in slot c ^ ((pl >> 2) & 3)
 #pragma unroll
       for (int nt2 = 0; nt2 < 2; ++nt2) {
-        const int m = px_base + wave * 32 + nt2 * 16 + l15;
-        if (m >= a.M) continue;
-        int bb, pix, ho, wo;
-        fast_divmod(m, HoWo, inv_howo, bb, pix);
-        fast_divmod(pix, a.Wo, inv_wo, ho, wo);
-        const int Y = 2 * ho + dy, X = 2 * wo + dx;
+        const int pl = nt2 * 16 + l15;
         half8 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -592,7 +601,20 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
           o[j] = m355_to_half(v0);
           o[4 + j] = m355_to_half(v1);
         }
-        *(half8*)((half_t*)a.y + (long)bb * a.y_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldy + g * 8) = o;
+        *(half8*)(ob + pl * 64 + ((g ^ ((pl >> 2) & 3)) << 4)) = o;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own LDS writes have landed (same-wave exchange: no barrier)
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const int qd = it * 64 + lane, pl = qd >> 2, c = qd & 3;
+        const half8 o = *(const half8*)(ob + pl * 64 + ((c ^ ((pl >> 2) & 3)) << 4));
+        const int m = px_base + wave * 32 + pl;
+        if (m >= a.M) continue;
+        int bb, pix, ho, wo;
+        fast_divmod(m, HoWo, inv_howo, bb, pix);
+        fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+        const int Y = 2 * ho + dy, X = 2 * wo + dx;
+        *(half8*)((half_t*)a.y + (long)bb * a.y_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldy + c * 8) = o;
       }
       __syncthreads();                                   // (persistent mode: the stages are reused by the next tile)
       continue;
@@ -795,6 +817,17 @@ int launch_variant(const ConvArgs& a, hipStream_t s) {
   auto k2 = conv_igemm_kernel<MT, NT, WCH, WPX, 2>;
   auto k3 = conv_igemm_kernel<MT, NT, WCH, WPX, 3>;
   auto k = a.ksize == 1 ? k1 : (a.ksize == 2 ? k2 : k3);
+  if constexpr (MT == 4 && NT == 4 && WCH == 2 && WPX == 2) {          // the special epilogues live in instantiations of their own
+    if (a.dec_preds) {
+      if (a.ksize != 1) return -1;
+      k = conv_igemm_kernel<MT, NT, WCH, WPX, 1, 1>;
+    } else if (a.phase && a.w2) {
+      if (a.ksize != 2) return -1;
+      k = conv_igemm_kernel<MT, NT, WCH, WPX, 2, 2>;
+    }
+  } else {
+    if (a.dec_preds || (a.phase && a.w2)) return -1;
+  }
   if (lds_bytes > 65536) {
     e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS + 8192);
     if (e != hipSuccess) return (int)e;
@@ -868,6 +901,12 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   if (a.ksize == 2 && a.phase && (a.stride != 1 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 64)) return -1;  // ... or a phase conv
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
   if (a.M >= (1 << 24)) return -1;  // fast_divmod range
+  // the loader keeps row offsets as 32-bit counts of 8 elements: every stride a multiple of 8, the input within 2^34 elements
+  if (a.x_bstride % 8 || (a.csplit > 0 && (a.x2_bstride % 8 || a.ldx2 % 8 || a.csplit % 8))) return -1;
+  {
+    const long nimg = a.Ho * a.Wo > 0 ? (a.M + (long)a.Ho * a.Wo - 1) / ((long)a.Ho * a.Wo) : 0;
+    if (nimg * a.x_bstride >= (1L << 34) || (a.csplit > 0 && nimg * a.x2_bstride >= (1L << 34))) return -1;
+  }
   int tile = force_tile & 0xff;
   if (force_tile < 0) tile = -1;
   if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
