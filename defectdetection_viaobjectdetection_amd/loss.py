@@ -244,7 +244,7 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
     # expectation over the 16 bins as multiply + reduce: `softmax @ bins` runs as a (B*A*4) x 16 rocBLAS gemv, 1.4 ms
     use_kernels = raw.is_cuda and _loss_kernels_enabled()
     with torch.no_grad():
-        if use_kernels:                                    # one pass over the raw rows (csrc/loss_kernels.hip)
+        if use_kernels and raw.shape[2] <= 255:            # one pass over the raw rows (csrc/loss_kernels.hip; 64 rows in LDS)
             boxes_px, scores = _decode_all(raw.detach(), anchors, k["strides_flat"], nc)
         else:
             ltrb = (logits_box.view(B, A, 4, REG_MAX).softmax(3) * bins).sum(3)

@@ -523,6 +523,8 @@ class TrainEngine:
                 if dz is None:
                     dz = op["_dz"] = torch.zeros((B, h * w, cp), dtype=torch.float16, device=self.dev)
                 dz[..., :cout].copy_(d_raw[:, lo:lo + h * w, op["ch_off"]:op["ch_off"] + cout])
+                if lo not in level_bias and d_raw.shape[2] > 256:           # (more than 160 classes: wider than the column-sum kernel)
+                    level_bias[lo] = d_raw[:, lo:lo + h * w, :].sum((0, 1))
                 if lo not in level_bias:
                     level_bias[lo] = self._colsum(d_raw.data_ptr() + lo * d_raw.shape[2] * 4, False, B, d_raw.shape[1] * d_raw.shape[2],
                                                   h * w, d_raw.shape[2], d_raw.shape[2], torch.empty(d_raw.shape[2], device=self.dev))
