@@ -307,19 +307,21 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
 
 
 class GraphedSegLoss:
-    """The loss and its backward as ONE hipGraph replay per step (stands where ``criterion(preds, batch)`` +
-    ``loss.backward()`` stand upstream, /root/reference/BscanBased/yolo_seg_train.py:12).
+    """The criterion of the training loop: loss + its backward on the engine's train-mode outputs (stands where
+    ``criterion(preds, batch)`` + ``loss.backward()`` stand upstream, /root/reference/BscanBased/yolo_seg_train.py:12).
 
-    ``loss_core`` forward + backward is ~230 small device kernels (4.2 ms of GPU time at batch 64) that take 5.8 ms of wall
-    time launched one by one: the host is the bottleneck.  For every padded-target width G seen, the first call warms up
-    eagerly, captures ``loss_core`` + ``backward`` on static input buffers, and later calls copy the inputs in and replay.
-    OPT-IN (``M355_LOSS_GRAPH=1``), eager by default: at the small shapes of the tests the replay equals the eager loss to
-    1e-5 and saves the launch overhead, but the one run at batch 64 @640 (tools/train_bench.py) ended in a GPU hardware
-    exception (HSA_STATUS_ERROR_EXCEPTION 0x1016) during the replayed steps; the cause was not found from that one failure
-    and the run was not repeated.  Also eager on CPU tensors and for batches without labels (G = 0).
+    ``prepare(batch, B, dev)`` pads the targets BEFORE the forward pass is enqueued (the loss's one host synchronisation);
+    ``__call__(raw, protos, prepared_or_batch, scale)`` -> (items (4,) [box, seg, cls, dfl], d(scale * loss)/d raw,
+    d(scale * loss)/d protos).  On device tensors the box / DFL / mask terms and the all-anchor decode are HIP kernels
+    (``csrc/loss_kernels.hip``) wrapped as autograd Functions; the assignment and the class BCE are torch ops.
 
-    ``__call__(raw, protos, batch, scale)`` -> (items (4,), d(scale * loss)/d raw, d(scale * loss)/d protos); the two
-    gradients are buffers of the graph, valid until the next call."""
+    hipGraph mode (the name): OPT-IN with ``M355_LOSS_GRAPH=1``, eager by default.  For every padded-target width G seen, the
+    first call warms up eagerly, captures ``loss_core`` + ``backward`` on static input buffers, and later calls copy the inputs
+    in and replay.  At the small shapes of the tests the replay equals the eager loss to 1e-5, but the one run at batch 64 @640
+    (tools/train_bench.py, round 2, before the loss kernels existed) ended in a GPU hardware exception
+    (HSA_STATUS_ERROR_EXCEPTION 0x1016) during the replayed steps; the cause was not found from that one failure and the run
+    was not repeated.  Since then the host no longer limits the loss (its launches are enqueued while the device is in the
+    forward convolutions), so the capture has little left to gain.  Also eager on CPU tensors and for batches without labels."""
 
     def __init__(self, nc: int, imgsz: Tuple[int, int], gains: Tuple[float, float, float] = (7.5, 0.5, 1.5)):
         import os
