@@ -18,6 +18,8 @@ bias-gradient sums).  Master parameters are fp32 in KRSC layout = the layout wgr
 from __future__ import annotations
 
 import ctypes as C
+import os
+from contextlib import contextmanager
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -60,6 +62,10 @@ class TrainEngine:
         self.zero_bias = torch.zeros(4096, dtype=torch.float32, device=self.dev)
         self.wgrad_ws = torch.empty(1 << 20, dtype=torch.float32, device=self.dev)   # split-K partial slabs (deterministic wgrad)
         self._colsum_ws = None                                                       # partial rows of the bias-gradient column sums
+        # weight gradients run on a side stream beside the input gradient of the same layer (both only read dZ): on the small
+        # maps neither kernel fills 256 CUs on its own.  M355_NO_WGRAD_STREAM=1: everything on the caller's stream.
+        self._wg_stream = None if os.environ.get("M355_NO_WGRAD_STREAM") == "1" else torch.cuda.Stream(device=self.dev)
+        self._wg_done = None                                                         # event after the last side-stream launch
         self._build()
 
     # ------------------------------------------------------------------ graph
@@ -291,6 +297,29 @@ class TrainEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
+    @contextmanager
+    def _beside(self, op):
+        """Run the enclosed launches (a layer's weight gradient and the copies behind it) on the side stream, after everything
+        enqueued so far on the caller's stream; `_join_side()` makes the caller's stream wait for them."""
+        if self._wg_stream is None:
+            yield
+            return
+        ev = op.get("_ev_fork")
+        if ev is None:
+            ev = op["_ev_fork"] = torch.cuda.Event()
+            op["_ev_join"] = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._wg_stream.wait_event(ev)
+        with torch.cuda.stream(self._wg_stream):
+            yield
+            op["_ev_join"].record(self._wg_stream)
+        self._wg_done = op["_ev_join"]
+
+    def _join_side(self):
+        if self._wg_done is not None:
+            torch.cuda.current_stream().wait_event(self._wg_done)
+            self._wg_done = None
+
     def _padded_bias(self, op, name: str) -> torch.Tensor:
         """The bias of a plain conv followed by 128 zeros (the kernels read whole channel tiles): a persistent buffer refreshed
         with one copy per step."""
@@ -337,6 +366,7 @@ class TrainEngine:
         a.dw, a.zero_page = dw.data_ptr(), self.zero_page.data_ptr()
         need = int(lib.m355_wgrad_workspace_bytes(self.B, ho, wo, cin, cout, k))
         if need > self.wgrad_ws.numel() * 4:                          # grows to the largest layer, then stays
+            torch.cuda.current_stream().synchronize()                  # (launches in flight still use the old workspace)
             self.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.dev)
         a.ws, a.ws_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel() * 4
         check(lib.m355_wgrad_launch(C.byref(a), self._stream()))
@@ -465,7 +495,8 @@ class TrainEngine:
         written[self.protos_t] = [(0, self.tensors[self.protos_t].shape[-1])]
         ready: List[str] = []
         for op in reversed(self.ops):
-            if on_ready is not None:                                        # gradients finished by the previous op
+            if on_ready is not None and ready:                              # gradients finished by the previous op
+                self._join_side()                                           # (its weight gradient ran on the side stream)
                 for k in ready:
                     on_ready(k)
             ready = []
@@ -500,12 +531,14 @@ class TrainEngine:
                 if s.cin == 3:
                     if "dw8" not in sv:
                         sv["dw8"] = torch.empty((cout, 3, 3, 8), device=self.dev)
-                    self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, 8, ho, wo, cout, s.k,
-                                       s.stride, s.k // 2, sv["dw8"])
-                    gw.copy_(sv["dw8"][..., :3])
+                    with self._beside(op):      # (every weight gradient on the one side stream: they share the split-K workspace)
+                        self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, 8, ho, wo, cout, s.k,
+                                           s.stride, s.k // 2, sv["dw8"])
+                        gw.copy_(sv["dw8"][..., :3])
                 else:
-                    self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, cin, ho, wo, cout, s.k,
-                                       s.stride, s.k // 2, gw)
+                    with self._beside(op):
+                        self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, cin, ho, wo, cout, s.k,
+                                           s.stride, s.k // 2, gw)
                     gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                     acc = 0 if self._claim(written, src) else gp
                     self._conv_launch(sv["dz"].data_ptr(), ho * wo * cout, cout, ho, wo, cout, self.packed[name + ":dgrad"],
@@ -531,14 +564,15 @@ class TrainEngine:
                 self.grads[f"{name}.bias"].copy_(level_bias[lo][op["ch_off"]:op["ch_off"] + cout])
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 gw = self.grads[f"{name}.weight"]
-                if cp == cout:                                              # KRSC rows = the gradient's own layout: no staging copy
-                    self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, gw)
-                else:
-                    dw = op.get("_dw")
-                    if dw is None:
-                        dw = op["_dw"] = torch.empty((cp, 1, 1, src.c), device=self.dev)
-                    self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, dw)
-                    gw.copy_(dw[:cout])
+                dw = op.get("_dw")
+                if cp != cout and dw is None:
+                    dw = op["_dw"] = torch.empty((cp, 1, 1, src.c), device=self.dev)
+                with self._beside(op):
+                    if cp == cout:                                          # KRSC rows = the gradient's own layout: no staging copy
+                        self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, gw)
+                    else:
+                        self._wgrad_launch(dz.data_ptr(), cp, h * w * cp, xp, xbs, ldx, h, w, src.c, h, w, cp, 1, 1, 0, dw)
+                        gw.copy_(dw[:cout])
                 ready += [f"{name}.bias", f"{name}.weight"]
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                 acc = 0 if self._claim(written, src) else gp
@@ -554,15 +588,17 @@ class TrainEngine:
                 self._colsum(gy.data_ptr(), True, 1, 0, B * 4 * h * w, cout, cout, self.grads[f"{name}.bias"])
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 # wgrad of the equivalent 2x2 / stride-2 conv (dY -> X): "dz" = X, "x" = dY -> [cin][(dy,dx),co]
-                dw = torch.empty((cin, 2, 2, cout), device=self.dev)
-                self._wgrad_launch(xp, ldx, xbs, gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, h, w, cin, 2, 2, 0, dw)
-                self.grads[f"{name}.weight"].copy_(dw.permute(0, 3, 1, 2))
+                dw = op.get("_dw")
+                if dw is None:
+                    dw = op["_dw"] = torch.empty((cin, 2, 2, cout), device=self.dev)
+                with self._beside(op):
+                    self._wgrad_launch(xp, ldx, xbs, gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, h, w, cin, 2, 2, 0, dw)
+                    self.grads[f"{name}.weight"].copy_(dw.permute(0, 3, 1, 2))
                 ready += [f"{name}.bias", f"{name}.weight"]
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                 acc = 0 if self._claim(written, src) else gp
                 self._conv_launch(gy.data_ptr(), 4 * h * w * cout, cout, 2 * h, 2 * w, cout, self.packed[name + ":dgrad"], gp,
                                   gbs, ldg, h, w, cin, 2, 2, 0, res_ptr=acc, r_bs=gbs, ldr=ldg)
-                op["_dw_keepalive"] = dw
             elif kind == "pool":                                           # SPPF: y1 = mp(a), y2 = mp(y1), y3 = mp(y2)
                 src, dst = op["src"], op["dst"]
                 c = src.c
@@ -595,6 +631,7 @@ class TrainEngine:
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                 check(lib.m355_upsample2x_bwd_launch(gyp, gybs, ldgy, gp, gbs, ldg, B, hs, ws_, src.c,
                                                      0 if self._claim(written, src) else 1, st))
+        self._join_side()
         if on_ready is not None:
             for k in ready:
                 on_ready(k)
