@@ -66,6 +66,9 @@ class TrainEngine:
         # maps neither kernel fills 256 CUs on its own.  M355_NO_WGRAD_STREAM=1: everything on the caller's stream.
         self._wg_stream = None if os.environ.get("M355_NO_WGRAD_STREAM") == "1" else torch.cuda.Stream(device=self.dev)
         self._wg_done = None                                                         # event after the last side-stream launch
+        # forward: the 1/8-level head + the prototype branch beside the rest of the neck (M355_NO_HEAD_STREAM=1: one stream)
+        self._head_stream = None if os.environ.get("M355_NO_HEAD_STREAM") == "1" else torch.cuda.Stream(device=self.dev)
+        self._head_ops = None
         self._build()
 
     # ------------------------------------------------------------------ graph
@@ -371,6 +374,71 @@ class TrainEngine:
         a.ws, a.ws_bytes = self.wgrad_ws.data_ptr(), self.wgrad_ws.numel() * 4
         check(lib.m355_wgrad_launch(C.byref(a), self._stream()))
 
+    def _fwd_op(self, op, update_running_stats: bool) -> None:
+        """Enqueue one forward op on the current stream."""
+        B = self.B
+        st = self._stream()
+        kind = op["kind"]
+        if kind == "conv":
+            name, src, dst = op["name"], op["src"], op["dst"]
+            tin, tout = self.tensors[src.t], self.tensors[dst.t]
+            hi, wi = tin.shape[1:3]
+            ho, wo = tout.shape[1:3]
+            cout = dst.c
+            sv = self.saved.setdefault(name, {})
+            if "z" not in sv:
+                sv["z"] = torch.empty((B, ho, wo, cout), dtype=torch.float16, device=self.dev)
+                sv["mean"] = torch.empty(cout, device=self.dev)
+                sv["invstd"] = torch.empty(cout, device=self.dev)
+                # per-block partial sums + ticket of the ordered batch-norm reductions: zeroed once, self-resetting
+                sv["ws"] = torch.zeros(int(lib.m355_bn_workspace_floats(cout)), device=self.dev)
+            xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+            self._conv_launch(xp, xbs, ldx, hi, wi, src.c, self.packed[name + ":fwd"], sv["z"].data_ptr(), ho * wo * cout,
+                              cout, ho, wo, cout, op["k"], op["s"], op["k"] // 2)
+            yp, _, ldy = self._slice_ptr(self.tensors, dst)
+            rp, ldr = (0, 0)
+            if op["res"] is not None:
+                rp, _, ldr = self._slice_ptr(self.tensors, op["res"])
+            rm = self.params[f"{name}.bn.running_mean"].data_ptr() if update_running_stats else 0
+            rv = self.params[f"{name}.bn.running_var"].data_ptr() if update_running_stats else 0
+            check(lib.m355_bn_train_fwd_launch(sv["z"].data_ptr(), B * ho * wo, cout, cout,
+                                               self.params[f"{name}.bn.weight"].data_ptr(),
+                                               self.params[f"{name}.bn.bias"].data_ptr(), BN_EPS, 1, yp, ldy, rp, ldr,
+                                               sv["mean"].data_ptr(), sv["invstd"].data_ptr(), sv["ws"].data_ptr(),
+                                               rm, rv, BN_MOMENTUM, st))
+        elif kind == "plain":
+            name, src = op["name"], op["src"]
+            tin = self.tensors[src.t]
+            h, w = op["hw"]
+            xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+            yp = self.raw.data_ptr() + (op["level_off"] * self.rw + op["ch_off"]) * 4
+            bias = self._padded_bias(op, name)
+            self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, self.A * self.rw, self.rw, h, w,
+                              op["cout"], 1, 1, 0, bias=bias, out_f32=1)
+        elif kind == "convt":
+            name, src, dst = op["name"], op["src"], op["dst"]
+            tin, tout = self.tensors[src.t], self.tensors[dst.t]
+            h, w = tin.shape[1:3]
+            xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+            yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
+            bias = self._padded_bias(op, name)
+            self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, ybs, ldy, h, w, 4 * dst.c, 1, 1, 0,
+                              bias=bias, convt_co=dst.c)
+        elif kind == "pool":
+            src, dst = op["src"], op["dst"]
+            t = self.tensors[src.t]
+            _, H, W, Ct = t.shape
+            xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+            yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
+            check(lib.m355_sppf_pool_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
+        elif kind == "up":
+            src, dst = op["src"], op["dst"]
+            t = self.tensors[src.t]
+            _, H, W, _ = t.shape
+            xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+            yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
+            check(lib.m355_upsample2x_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
+
     # ------------------------------------------------------------------ forward
     def forward(self, images_u8_nhwc: torch.Tensor, update_running_stats: bool = True):
         """images uint8 (B,H,W,3) on the device.  Returns raw (B,A,64+nc+32) fp32 and protos (B,H/4,W/4,32) fp16
@@ -381,67 +449,34 @@ class TrainEngine:
         st = self._stream()
         # (u8 / 255) -> fp16 into the 8-channel input rows in one pass (was float(), div, half(), strided copy: 0.55 ms at b64)
         check(lib.m355_u8_to_f16x8_launch(images_u8_nhwc.contiguous().data_ptr(), x8.data_ptr(), x8.numel() // 8, st))
-        for op in self.ops:
-            kind = op["kind"]
-            if kind == "conv":
-                name, src, dst = op["name"], op["src"], op["dst"]
-                tin, tout = self.tensors[src.t], self.tensors[dst.t]
-                hi, wi = tin.shape[1:3]
-                ho, wo = tout.shape[1:3]
-                cout = dst.c
-                sv = self.saved.setdefault(name, {})
-                if "z" not in sv:
-                    sv["z"] = torch.empty((B, ho, wo, cout), dtype=torch.float16, device=self.dev)
-                    sv["mean"] = torch.empty(cout, device=self.dev)
-                    sv["invstd"] = torch.empty(cout, device=self.dev)
-                    # per-block partial sums + ticket of the ordered batch-norm reductions: zeroed once, self-resetting
-                    sv["ws"] = torch.zeros(int(lib.m355_bn_workspace_floats(cout)), device=self.dev)
-                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
-                self._conv_launch(xp, xbs, ldx, hi, wi, src.c, self.packed[name + ":fwd"], sv["z"].data_ptr(), ho * wo * cout,
-                                  cout, ho, wo, cout, op["k"], op["s"], op["k"] // 2)
-                yp, _, ldy = self._slice_ptr(self.tensors, dst)
-                rp, ldr = (0, 0)
-                if op["res"] is not None:
-                    rp, _, ldr = self._slice_ptr(self.tensors, op["res"])
-                rm = self.params[f"{name}.bn.running_mean"].data_ptr() if update_running_stats else 0
-                rv = self.params[f"{name}.bn.running_var"].data_ptr() if update_running_stats else 0
-                check(lib.m355_bn_train_fwd_launch(sv["z"].data_ptr(), B * ho * wo, cout, cout,
-                                                   self.params[f"{name}.bn.weight"].data_ptr(),
-                                                   self.params[f"{name}.bn.bias"].data_ptr(), BN_EPS, 1, yp, ldy, rp, ldr,
-                                                   sv["mean"].data_ptr(), sv["invstd"].data_ptr(), sv["ws"].data_ptr(),
-                                                   rm, rv, BN_MOMENTUM, st))
-            elif kind == "plain":
-                name, src = op["name"], op["src"]
-                tin = self.tensors[src.t]
-                h, w = op["hw"]
-                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
-                yp = self.raw.data_ptr() + (op["level_off"] * self.rw + op["ch_off"]) * 4
-                bias = self._padded_bias(op, name)
-                self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, self.A * self.rw, self.rw, h, w,
-                                  op["cout"], 1, 1, 0, bias=bias, out_f32=1)
-            elif kind == "convt":
-                name, src, dst = op["name"], op["src"], op["dst"]
-                tin, tout = self.tensors[src.t], self.tensors[dst.t]
-                h, w = tin.shape[1:3]
-                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
-                yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
-                bias = self._padded_bias(op, name)
-                self._conv_launch(xp, xbs, ldx, h, w, src.c, self.packed[name + ":fwd"], yp, ybs, ldy, h, w, 4 * dst.c, 1, 1, 0,
-                                  bias=bias, convt_co=dst.c)
-            elif kind == "pool":
-                src, dst = op["src"], op["dst"]
-                t = self.tensors[src.t]
-                _, H, W, Ct = t.shape
-                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
-                yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
-                check(lib.m355_sppf_pool_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
-            elif kind == "up":
-                src, dst = op["src"], op["dst"]
-                t = self.tensors[src.t]
-                _, H, W, _ = t.shape
-                xp, xbs, ldx = self._slice_ptr(self.tensors, src)
-                yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
-                check(lib.m355_upsample2x_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
+        side = self._head_stream
+        if side is not None and self._head_ops is None and not any(o.get("name") == "model.15.cv2" for o in self.ops):
+            side = self._head_stream = None                                 # (a graph without that fork point: one stream)
+        if side is None:
+            for op in self.ops:
+                self._fwd_op(op, update_running_stats)
+        else:
+            # The head of the 1/8 level and the prototype branch (the large-map half of the head) need only model.15's output:
+            # they go to a side stream while this stream walks the rest of the neck (40x40 / 20x20 maps that leave most CUs idle)
+            # and the two smaller head levels.  The backward pass keeps the list order (its accumulations are ordered).
+            if self._head_ops is None:
+                self._head_ops = [o for o in self.ops if o.get("name", "").startswith(("model.22.cv2.0.", "model.22.cv3.0.",
+                                                                                       "model.22.cv4.0.", "model.22.proto."))]
+                for o in self._head_ops:
+                    o["_side"] = True
+                self._head_fork, self._head_join = torch.cuda.Event(), torch.cuda.Event()
+            for op in self.ops:
+                if op.get("_side"):
+                    continue
+                self._fwd_op(op, update_running_stats)
+                if op.get("name") == "model.15.cv2":
+                    self._head_fork.record(torch.cuda.current_stream())
+                    side.wait_event(self._head_fork)
+                    with torch.cuda.stream(side):
+                        for hop in self._head_ops:
+                            self._fwd_op(hop, update_running_stats)
+                        self._head_join.record(side)
+            torch.cuda.current_stream().wait_event(self._head_join)
         return self.raw, self.tensors[self.protos_t]
 
     # ------------------------------------------------------------------ backward
