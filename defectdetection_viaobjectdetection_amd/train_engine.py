@@ -61,7 +61,7 @@ class TrainEngine:
         self.zero_page = torch.zeros(256, dtype=torch.uint8, device=self.dev)
         self.zero_bias = torch.zeros(4096, dtype=torch.float32, device=self.dev)
         self.wgrad_ws = torch.empty(1 << 20, dtype=torch.float32, device=self.dev)   # split-K partial slabs (deterministic wgrad)
-        self._colsum_ws = None                                                       # partial rows of the bias-gradient column sums
+        self._colsum_ws: Dict[int, torch.Tensor] = {}                                # partial rows of the bias-gradient column sums
         # weight gradients run on a side stream beside the input gradient of the same layer (both only read dZ): on the small
         # maps neither kernel fills 256 CUs on its own.  M355_NO_WGRAD_STREAM=1: everything on the caller's stream.
         self._wg_stream = None if os.environ.get("M355_NO_WGRAD_STREAM") == "1" else torch.cuda.Stream(device=self.dev)
@@ -336,10 +336,12 @@ class TrainEngine:
     def _colsum(self, src_ptr: int, f16: bool, nb: int, bstride: int, rows: int, ld: int, cols: int, out: torch.Tensor) -> torch.Tensor:
         """out[c] = sum over (b, r) of src[b * bstride + r * ld + c] in a fixed order (bias gradients); out fp32 contiguous."""
         need = int(lib.m355_colsum_workspace_floats(nb, cols))
-        if self._colsum_ws is None or self._colsum_ws.numel() < need:
-            self._colsum_ws = torch.empty(need, dtype=torch.float32, device=self.dev)
+        key = torch.cuda.current_stream().cuda_stream                       # one workspace per stream that runs column sums
+        ws = self._colsum_ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._colsum_ws[key] = torch.empty(need, dtype=torch.float32, device=self.dev)
         assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == cols
-        check(lib.m355_colsum_launch(src_ptr, 1 if f16 else 0, nb, bstride, rows, ld, cols, self._colsum_ws.data_ptr(), out.data_ptr(),
+        check(lib.m355_colsum_launch(src_ptr, 1 if f16 else 0, nb, bstride, rows, ld, cols, ws.data_ptr(), out.data_ptr(),
                                      self._stream()))
         return out
 
@@ -529,7 +531,10 @@ class TrainEngine:
         self.gtensors[self.protos_t].copy_(d_protos.to(torch.float16))
         written[self.protos_t] = [(0, self.tensors[self.protos_t].shape[-1])]
         ready: List[str] = []
-        for op in reversed(self.ops):
+
+        def run(op):
+            nonlocal ready
+            st = self._stream()                                             # (the stream this op is enqueued on)
             if on_ready is not None and ready:                              # gradients finished by the previous op
                 self._join_side()                                           # (its weight gradient ran on the side stream)
                 for k in ready:
@@ -666,6 +671,31 @@ class TrainEngine:
                 gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                 check(lib.m355_upsample2x_bwd_launch(gyp, gybs, ldgy, gp, gbs, ldg, B, hs, ws_, src.c,
                                                      0 if self._claim(written, src) else 1, st))
+
+        ops_rev = list(reversed(self.ops))
+        side = self._head_stream if (on_ready is None and self._head_ops) else None
+        if side is None:
+            for op in ops_rev:
+                run(op)
+        else:
+            # The backward of the 1/8-level head + prototype branch (large maps) on the head stream beside the backward of the two
+            # smaller head levels on this one: they write disjoint gradient tensors (model.15's output vs model.18's / model.21's)
+            # and each stream keeps the list order among its own ops, so every accumulation happens in the order of the
+            # one-stream pass.  Joined before the neck's backward starts.  (One stream when a gradient reducer is attached.)
+            head_rest = [o for o in ops_rev if o.get("name", "").startswith("model.22.") and not o.get("_side")]
+            self._head_fork.record(torch.cuda.current_stream())
+            side.wait_event(self._head_fork)
+            with torch.cuda.stream(side):
+                for op in ops_rev:
+                    if op.get("_side"):
+                        run(op)
+                self._head_join.record(side)
+            for op in head_rest:
+                run(op)
+            torch.cuda.current_stream().wait_event(self._head_join)
+            for op in ops_rev:
+                if not op.get("name", "").startswith("model.22."):
+                    run(op)
         self._join_side()
         if on_ready is not None:
             for k in ready:
