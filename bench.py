@@ -331,7 +331,10 @@ def train_step_bench(world, dist, steps=4, warm=2):
         ev[2].record()
         if reducer is not None and comm:
             reducer.reset()
-        eng.backward(d_raw, d_protos, on_ready=reducer.mark_ready if (reducer is not None and comm and overlap) else None)
+        # N > 1: the pass without the exchange reports through a no-op callback, so that both passes enqueue the backward the same
+        # way (with a callback attached TrainEngine keeps the head's backward on one stream) and their difference is the exchange
+        cb = None if reducer is None else (reducer.mark_ready if (comm and overlap) else (lambda name: None))
+        eng.backward(d_raw, d_protos, on_ready=cb)
         if reducer is not None and comm:
             reducer.finish()
         ev[3].record()
