@@ -64,10 +64,20 @@ class TrainEngine:
         self._colsum_ws: Dict[int, torch.Tensor] = {}                                # partial rows of the bias-gradient column sums
         # weight gradients run on a side stream beside the input gradient of the same layer (both only read dZ): on the small
         # maps neither kernel fills 256 CUs on its own.  M355_NO_WGRAD_STREAM=1: everything on the caller's stream.
-        self._wg_stream = None if os.environ.get("M355_NO_WGRAD_STREAM") == "1" else torch.cuda.Stream(device=self.dev)
+        # Side streams only in a single-process job.  With two ranks sharing one GPU (the gloo rehearsal of the N > 1 path) every
+        # cross-stream dependency waited for a queue time slice: 13 s per step instead of 0.16 s; on one GPU per rank that
+        # should not happen, but it cannot be verified here, so a multi-rank job keeps the one-stream order it was tested with
+        # (M355_SIDE_STREAMS=1 forces them on).
+        import torch.distributed as _dist
+        multi = _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1
+        if multi and os.environ.get("M355_SIDE_STREAMS") != "1":
+            os_no_side = True
+        else:
+            os_no_side = False
+        self._wg_stream = None if (os_no_side or os.environ.get("M355_NO_WGRAD_STREAM") == "1") else torch.cuda.Stream(device=self.dev)
         self._wg_done = None                                                         # event after the last side-stream launch
         # forward: the 1/8-level head + the prototype branch beside the rest of the neck (M355_NO_HEAD_STREAM=1: one stream)
-        self._head_stream = None if os.environ.get("M355_NO_HEAD_STREAM") == "1" else torch.cuda.Stream(device=self.dev)
+        self._head_stream = None if (os_no_side or os.environ.get("M355_NO_HEAD_STREAM") == "1") else torch.cuda.Stream(device=self.dev)
         self._head_ops = None
         self._build()
 
