@@ -59,13 +59,14 @@ def main():
                          "~8 us of serialisation, ~0.6 ms per fully instrumented step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))     # plain `python bench.py --gpus N`: one child launcher, before any GPU call
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # M355_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices)
     backend = os.environ.get("M355_DIST_BACKEND", "nccl")
     if backend != "nccl":
@@ -80,9 +81,8 @@ def main():
         else:
             dist.init_process_group(backend)
 
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from helpers import synthetic_bscans
     from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.synthetic import synthetic_bscans
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
 
     B = args.batch
@@ -250,7 +250,7 @@ def main():
                 roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None}
             roof["flop_per_byte"] = round(intensity, 1)
-            roof["traffic"] = pmc_traffic(dom)
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(dom)
             roof["launches_per_step"] = d["launches"] // max(sampled, 1)
             roof["event_sampled_steps"] = sampled
             roof["avg_launch_us"] = round(1e3 * d["ms"] / max(d["launches"], 1), 2)
@@ -282,6 +282,23 @@ def main():
         dist.destroy_process_group()
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher environment: start `python -m torch.distributed.run --nproc-per-node N
+    bench.py <same arguments>` as a CHILD process (nothing in this process has touched the GPU, and it never will), let
+    its output through (rank 0 prints the JSON line) and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def train_step_bench(world, dist, steps=4, warm=2):
     """One optimizer step of the training path on a synthetic device-resident batch (images + 2 boxes / masks per image).
     N=1: YOLOv8s-seg, batch 64 @640 (BASELINE config 3); N>1: YOLOv8m-seg, 64 images per GPU, data parallel (config 4).
@@ -290,7 +307,7 @@ def train_step_bench(world, dist, steps=4, warm=2):
     import numpy as np
     import torch
     from defectdetection_viaobjectdetection_amd._capi import check, lib
-    from defectdetection_viaobjectdetection_amd.loss import GraphedSegLoss
+    from defectdetection_viaobjectdetection_amd.loss import SegCriterion
     from defectdetection_viaobjectdetection_amd.sharding import GradBucketReducer
     from defectdetection_viaobjectdetection_amd.spec import init_state_dict
     from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
@@ -308,7 +325,7 @@ def train_step_bench(world, dist, steps=4, warm=2):
     masks[:, 60:70, 60:70] = 2
     # labels as a loader hands them over: the small per-instance tensors on the host, the mask maps already on the device
     batch = {"batch_idx": torch.arange(B).repeat_interleave(2).float(), "cls": torch.zeros(n), "bboxes": boxes.cpu(), "masks": masks}
-    criterion = GraphedSegLoss(1, (S, S))
+    criterion = SegCriterion(1, (S, S))
     m1 = torch.zeros(eng.n_train, device=dev)
     m2 = torch.zeros(eng.n_train, device=dev)
     ema = eng.flat_params.clone()
@@ -394,17 +411,20 @@ def train_step_bench(world, dist, steps=4, warm=2):
 
 
 def pmc_traffic(kernel_label):
-    """HBM bytes per launch of `kernel_label` from the committed rocprofv3 PMC passes of this same command
-    (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE), or None."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            k = json.load(f)["kernels"].get(kernel_label)
-        return None if k is None else round(k["hbm_bytes_per_launch"])
-    except (OSError, ValueError, KeyError):
-        return None
+    """(HBM bytes per launch of `kernel_label`, the file they come from): the newest committed rocprofv3 PMC pass of this
+    same command under profiles/ (rNN_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE).  Not
+    measured in this run -- counters need their own rocprofv3 passes -- so the line names its source; (None, None) if the
+    newest pass does not hold the kernel."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                k = json.load(f)["kernels"].get(kernel_label)
+        except (OSError, ValueError, KeyError):
+            continue
+        if k is not None:
+            return round(k["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+    return None, None
 
 
 def host_cores():
@@ -427,7 +447,7 @@ def cpu_baseline(scale, sd):
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import yolov8_seg_oracle as orc
-    from helpers import synthetic_bscans
+    from defectdetection_viaobjectdetection_amd.synthetic import synthetic_bscans
     cores = host_cores()
     torch.set_num_threads(cores)
     model = orc.SegmentationModel(scale, 1)

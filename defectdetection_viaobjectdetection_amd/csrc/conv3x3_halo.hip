@@ -382,8 +382,7 @@ int launch_conv3x3_halo(const ConvArgs& a0, int variant, hipStream_t s) {
       (a.Cout > 64 || a.Hi * a.Wi <= 1600))
     return launch_conv3x3_m32(a, 0, s);
   if (variant == 3 || (variant == 0 && conv3x3_wide_ok(a) && !knobs().no_wide)) return launch_conv3x3_wide(a, s);
-  if (variant >= 5) return launch_conv3x3_lean(a, variant - 5, s);
-  if (variant == 0 && knobs().lean) return launch_conv3x3_lean(a, 0, s);   // measured equal to the K-64 kernels below
+  if (variant >= 5) return -1;   // ids 21-24 were the lean halo template (measured equal to the K-64 kernels below; removed in round 3)
   if (variant == 0) {
     variant = knobs().halo_variant;  // measured: the 4-wave variant (two blocks per CU) wins on every layer
     if (variant != 1 && variant != 2) variant = 2;

@@ -1,7 +1,7 @@
 // 3x3 / stride-1 / pad-1 NHWC fp16 convolution for NARROW maps (W <= 26: the 20x20 level at 640x640 input), where a
 // 16-pixel-wide tile wastes 38-60 % of its columns and the layers fell back to the im2col kernel (which re-streams the
 // input nine times through the 30 B/clk/CU LDS intake: 16 % MFMA share on 256 -> 256 @ 20x20).
-// Same pipeline as conv3x3_lean.hip (32-deep K steps in rows of three taps, weight ring slot = kw, affine patch pieces
+// Same pipeline as the wide kernel's small-tile form (32-deep K steps in rows of three taps, weight ring slot = kw, affine patch pieces
 // through a zero page, persistent tile walk, epilogue under the next prologue), different geometry:
 //   * a tile is a SLAB of R full-width image rows (R x W <= 256 pixels, R <= 10) x 64 channels; the MFMA pixel groups
 //     are 16 CONSECUTIVE pixels of the slab in row-major order, so a group may straddle two image rows and no column

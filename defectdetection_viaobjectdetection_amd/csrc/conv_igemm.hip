@@ -843,7 +843,6 @@ const Knobs& knobs() {
     Knobs v{};
     v.no_fast_epi = getenv("M355_NO_FAST_EPI") != nullptr;
     v.no_wide = getenv("M355_NO_WIDE") != nullptr;
-    v.lean = getenv("M355_LEAN") != nullptr;
     v.no_m32 = getenv("M355_NO_M32") != nullptr;
     v.no_bias_lds = getenv("M355_NO_BIAS_LDS") != nullptr;
     v.static_tiles = getenv("M355_STATIC_TILES") != nullptr;   // persistent kernels: static tile walk instead of the queue
@@ -877,9 +876,9 @@ bool conv_forced_tile_extent(int tile, int cout, int* bch, int* bpx) {
     case TILE_64x128: case TILE_64x128W8: c = 64; p = 128; break;
     case TILE_32x256: c = 32; p = 256; break;
     case TILE_64x256: c = 64; p = 256; break;
-    case TILE_HALO: case TILE_HALO8W: case TILE_HALO4W: case TILE_LEAN: c = cout > 64 ? 128 : 64; p = 128; break;
-    case TILE_HALOWIDE: case TILE_LEAN128x8: case TILE_LEAN128x16: c = 128; p = 256; break;
-    case TILE_LEAN64x16: case TILE_SLAB: c = 64; p = 256; break;
+    case TILE_HALO: case TILE_HALO8W: case TILE_HALO4W: c = cout > 64 ? 128 : 64; p = 128; break;
+    case TILE_HALOWIDE: c = 128; p = 256; break;
+    case TILE_SLAB: c = 64; p = 256; break;
     case TILE_C32: c = 32; p = 256; break;
     case TILE_M32: c = cout > 64 ? 128 : 64; p = 256; break;
     case TILE_M32_128: c = 128; p = 128; break;

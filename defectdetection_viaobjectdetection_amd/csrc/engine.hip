@@ -852,8 +852,6 @@ void annotate_ops(m355_engine* e) {
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_wide<128ch,16x16px>");
         else if (m32)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_m32<%s,8x16px>", cout_v > 64 ? "128ch" : "64ch");
-        else if (op.tile == TILE_HALO && getenv("M355_LEAN"))
-          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_lean<%s>", cout_v > 64 ? "128ch,8x16px" : "64ch,16x16px");
         else if (op.tile == TILE_HALO)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_halo<%s>", cout_v > 64 ? "128ch" : "64ch");
         else

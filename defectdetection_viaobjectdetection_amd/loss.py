@@ -92,7 +92,7 @@ _CONST_CACHE: Dict = {}
 
 def _consts(imgsz: Tuple[int, int], mh: int, mw: int, dev, gains: Tuple[float, float, float]):
     """Small constant tensors of the loss, built once per (image size, map size, device, gains): creating them inside the loss
-    would be host-to-device copies on every step (and is not allowed while a hipGraph is being captured)."""
+    would be host-to-device copies on every step."""
     key = (tuple(imgsz), mh, mw, str(dev), tuple(float(g) for g in gains))
     c = _CONST_CACHE.get(key)
     if c is None:
@@ -229,8 +229,7 @@ class _MaskTerm(torch.autograd.Function):
 
 def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_boxes: torch.Tensor, gt_valid: torch.Tensor,
               masks: torch.Tensor, nc: int, imgsz: Tuple[int, int], gains: Tuple[float, float, float] = (7.5, 0.5, 1.5)):
-    """The loss on padded targets: fixed shapes for a given G, no host synchronisation, no host-to-device copy -- the part
-    GraphedSegLoss captures in a hipGraph."""
+    """The loss on padded targets: fixed shapes for a given G, no host synchronisation, no host-to-device copy."""
     dev = raw.device
     B, A, _ = raw.shape
     mh, mw = protos.shape[1:3]
@@ -306,7 +305,7 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
     return items.sum() * B, items.detach()
 
 
-class GraphedSegLoss:
+class SegCriterion:
     """The criterion of the training loop: loss + its backward on the engine's train-mode outputs (stands where
     ``criterion(preds, batch)`` + ``loss.backward()`` stand upstream, /root/reference/BscanBased/yolo_seg_train.py:12).
 
@@ -315,59 +314,20 @@ class GraphedSegLoss:
     d(scale * loss)/d protos).  On device tensors the box / DFL / mask terms and the all-anchor decode are HIP kernels
     (``csrc/loss_kernels.hip``) wrapped as autograd Functions; the assignment and the class BCE are torch ops.
 
-    hipGraph mode (the name): OPT-IN with ``M355_LOSS_GRAPH=1``, eager by default.  For every padded-target width G seen, the
-    first call warms up eagerly, captures ``loss_core`` + ``backward`` on static input buffers, and later calls copy the inputs
-    in and replay.  At the small shapes of the tests the replay equals the eager loss to 1e-5, but the one run at batch 64 @640
-    (tools/train_bench.py, round 2, before the loss kernels existed) ended in a GPU hardware exception
-    (HSA_STATUS_ERROR_EXCEPTION 0x1016) during the replayed steps; the cause was not found from that one failure and the run
-    was not repeated.  Since then the host no longer limits the loss (its launches are enqueued while the device is in the
-    forward convolutions), so the capture has little left to gain.  Also eager on CPU tensors and for batches without labels."""
+    Rounds 1-2 also carried a hipGraph capture of loss + backward (``GraphedSegLoss``, opt-in).  Its one run at batch 64 @640
+    ended in a GPU hardware exception (HSA_STATUS_ERROR_EXCEPTION 0x1016) during the replays and the cause could not be
+    established from that one failure; since the host no longer limits the loss (its launches are enqueued while the device
+    is still in the forward convolutions) the capture had nothing left to gain, so it was deleted in round 3 rather than
+    shipped as known-faulting code."""
 
     def __init__(self, nc: int, imgsz: Tuple[int, int], gains: Tuple[float, float, float] = (7.5, 0.5, 1.5)):
-        import os
         self.nc, self.imgsz, self.gains = nc, tuple(imgsz), tuple(gains)
-        self.enabled = os.environ.get("M355_LOSS_GRAPH") == "1"
-        self._states: Dict = {}
-
-    def _eager(self, raw, protos, gt, masks, scale):
-        r = raw.detach().requires_grad_(True)             # shares the engine's buffer: the loss never writes to its inputs
-        # on the device the prototypes stay fp16 (the engine's own buffer): the mask kernel reads them as they are and the
-        # gradient comes back in the dtype TrainEngine.backward stores anyway
-        p = (protos.detach() if protos.is_cuda else protos.detach().float()).requires_grad_(True)
-        loss, items = loss_core(r, p, *gt, masks, self.nc, self.imgsz, self.gains)
-        (loss * scale).backward()
-        return items, r.grad, p.grad
-
-    def _capture(self, raw, protos, gt, masks):
-        st = dict(r=raw.detach().clone().requires_grad_(True), p=protos.detach().float().requires_grad_(True),
-                  gt=[t.clone() for t in gt], masks=masks.clone(), scale=torch.ones((), device=raw.device))
-
-        def run():
-            loss, items = loss_core(st["r"], st["p"], *st["gt"], st["masks"], self.nc, self.imgsz, self.gains)
-            (loss * st["scale"]).backward()
-            return items
-
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm-up off the capture: lazy initialisation, autograd buffers
-            for _ in range(2):
-                st["r"].grad = None
-                st["p"].grad = None
-                run()
-        torch.cuda.current_stream().wait_stream(side)
-        st["r"].grad = None                                # so that the gradients are allocated from the graph's pool
-        st["p"].grad = None
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            st["items"] = run()
-        st["graph"] = g
-        return st
 
     def prepare(self, batch: Dict[str, torch.Tensor], B: int, dev) -> Dict[str, torch.Tensor]:
         """The padded targets of a batch, to be made BEFORE the forward pass is enqueued and handed to ``__call__`` in place of
         the batch.  ``pad_targets`` holds the loss's one host synchronisation (the padded width G): on host labels it runs on
         the CPU and only the three padded tensors are uploaded; on device labels it waits for an idle stream instead of for
-        the whole forward pass -- either way the host can enqueue the ~500 small kernels of the loss while the device is still
+        the whole forward pass -- either way the host can enqueue the small kernels of the loss while the device is still
         in the forward convolutions."""
         dev = torch.device(dev)
         gt = pad_targets(batch, B, self.imgsz, batch["batch_idx"].device)
@@ -377,20 +337,10 @@ class GraphedSegLoss:
         dev = raw.device
         gt = batch["_gt"] if "_gt" in batch else pad_targets(batch, raw.shape[0], self.imgsz, dev)
         masks = batch["masks"].to(dev)
-        G = gt[1].shape[1]
-        if not (self.enabled and raw.is_cuda and G > 0):
-            return self._eager(raw, protos, gt, masks, scale)
-        key = (G, tuple(raw.shape), tuple(protos.shape), masks.dtype)
-        st = self._states.get(key)
-        if st is None:
-            st = self._states[key] = self._capture(raw, protos, gt, masks)
-        with torch.no_grad():
-            st["r"].copy_(raw)
-            st["p"].copy_(protos)
-            for d, s_ in zip(st["gt"], gt):
-                d.copy_(s_)
-            st["masks"].copy_(masks)
-            st["scale"].fill_(float(scale))
-        st["graph"].replay()
-        return st["items"], st["r"].grad, st["p"].grad
-
+        r = raw.detach().requires_grad_(True)             # shares the engine's buffer: the loss never writes to its inputs
+        # on the device the prototypes stay fp16 (the engine's own buffer): the mask kernel reads them as they are and the
+        # gradient comes back in the dtype TrainEngine.backward stores anyway
+        p = (protos.detach() if protos.is_cuda else protos.detach().float()).requires_grad_(True)
+        loss, items = loss_core(r, p, *gt, masks, self.nc, self.imgsz, self.gains)
+        (loss * scale).backward()
+        return items, r.grad, p.grad

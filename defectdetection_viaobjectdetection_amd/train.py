@@ -32,7 +32,7 @@ import torch
 from . import metrics as M
 from ._capi import check, lib
 from .dataset import SegDataset, epoch_batches, rasterize_polygon, read_data_yaml
-from .loss import GraphedSegLoss
+from .loss import SegCriterion
 from .sharding import GradBucketReducer
 
 DEFAULTS = dict(optimizer="auto", lr0=0.01, lrf=0.01, momentum=0.937, weight_decay=5e-4, warmup_epochs=3.0,
@@ -285,7 +285,7 @@ def train(model, data=None, epochs=100, imgsz=640, batch=16, project=None, name=
     acc = torch.zeros(n_train, device=dev)
     sumsq = torch.zeros(int(lib.m355_grad_sumsq_workspace_floats()), device=dev)   # [0] sum g^2, [1] non-finite count, then workspace
     reducer = GradBucketReducer(flat_g, eng.grad_spans(), bucket_bytes=int(a.bucket_mb) << 20) if world > 1 else None
-    criterion = GraphedSegLoss(model.nc, (imgsz, imgsz), (a.box, a.cls, a.dfl))
+    criterion = SegCriterion(model.nc, (imgsz, imgsz), (a.box, a.cls, a.dfl))
 
     nb = len(epoch_batches(len(train_ds), local_batch, 0, a.seed, rank, world))
     opt_name = str(a.optimizer).lower()

@@ -97,11 +97,11 @@ def test_forward_parity(setup_s, cuda_device):
     assert q(dsc, .99) <= 2e-3 and q(dbx, .99) <= 0.5
     # the maxima: a 60-layer fp16-storage network is chaotic at the ulp level, so the bound is what
     # the number format itself costs on these inputs -- an independent CPU implementation in the same format, measured here
-    # (maxima of a heavy-tailed noise: x 2; the rms, a stable statistic: x 1.25)
-    assert vo["dscore"] <= 2 * fo["dscore"] and vo["dbox"] <= 2 * fo["dbox"] and vo["cls"] <= 2 * fo["cls"]
+    # (maxima of a heavy-tailed noise: x 1.5 -- measured 0.99 x (score), 0.90 x (box), 1.03 x (class logit); the rms, a stable statistic: x 1.25)
+    assert vo["dscore"] <= 1.5 * fo["dscore"] and vo["dbox"] <= 1.5 * fo["dbox"] and vo["cls"] <= 1.5 * fo["cls"]
     assert g_cls_rms <= 1.25 * fo["cls_rms"] + 1e-4
     # two implementations of the same format are as far from each other as each is from fp32, not closer
-    assert vf["dscore"] <= 2 * fo["dscore"] and vf["dbox"] <= 2 * fo["dbox"]
+    assert vf["dscore"] <= 1.5 * fo["dscore"] and vf["dbox"] <= 1.5 * fo["dbox"]
 
 
 def test_decode_parity_same_raw(setup_s, cuda_device):

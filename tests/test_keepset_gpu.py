@@ -108,7 +108,7 @@ def test_prediction_maxima_within_the_format_floor(runs):
     d = np.abs(runs["gpu"]["preds"][..., 4] - runs["fp32"]["preds"][..., 4]).ravel()
     print(f"over {B}x8400 anchors -- format floor: score max {fs:.2e}, box max {fb:.3f} px, pair IoU max {fi:.2e};  HIP vs fp32: score max "
           f"{gs:.2e} (p99.9 {np.quantile(d, .999):.2e}), box max {gb:.3f} px;  HIP vs format oracle: score {hs:.2e}, box {hb:.3f} px")
-    assert gs <= 2 * fs and gb <= 2 * fb and hs <= 2 * fs and hb <= 2 * fb      # maxima of a heavy-tailed noise: x 2
+    assert gs <= 1.5 * fs and gb <= 1.5 * fb and hs <= 1.5 * fs and hb <= 1.5 * fb      # maxima of a heavy-tailed noise: x 1.5
     assert np.quantile(d, .99) <= 2e-3                       # SURVEY 8d's stated score tolerance, 99 % of the anchors
 
 

@@ -103,11 +103,11 @@ def test_assigner_picks_at_most_one_gt_per_anchor():
 
 
 def test_targets_prepared_ahead_give_the_same_loss_and_gradients():
-    """GraphedSegLoss.prepare (the padded targets made before the forward pass is enqueued, train.py) + __call__ on the prepared
+    """SegCriterion.prepare (the padded targets made before the forward pass is enqueued, train.py) + __call__ on the prepared
     dict == __call__ on the batch itself, items and both gradients bit for bit; also for a batch with an image without labels."""
     for empty in (False, True):
         raw, protos, batch, _ = _case(4, 3, 2, (64, 96), 3, empty)
-        crit = L.GraphedSegLoss(2, (64, 96))
+        crit = L.SegCriterion(2, (64, 96))
         i1, gr1, gp1 = crit(raw, protos, batch, 8.0)
         prep = crit.prepare(batch, 3, "cpu")
         assert set(prep) == {"_gt", "masks"} and prep["_gt"][1].shape[0] == 3

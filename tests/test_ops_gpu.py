@@ -77,18 +77,6 @@ CONV_CASES = [
     (2, 32, 32, 32, 32, 3, 1, 1, True, 20),         # residual, full tiles
     (3, 72, 56, 32, 32, 3, 1, 1, False, 20),        # partial spatial tiles
     (1, 160, 160, 32, 32, 3, 1, 0, False, 20),      # several tiles per block is exercised by the engine tests; no act
-    # lean halo template (conv3x3_lean.hip): 22 = 128 ch x 8x16 px, 23 = 64 ch x 16x16 px, 24 = 128 ch x 16x16 px
-    (2, 40, 40, 128, 128, 3, 1, 1, True, 22),       # the layer shape it is meant for: 2.5 column tiles
-    (1, 80, 80, 128, 224, 3, 1, 1, False, 22),      # ragged channel tile
-    (2, 72, 56, 64, 128, 3, 1, 1, True, 22),        # 2 chunks, partial tiles in both directions
-    (4, 160, 160, 64, 128, 3, 1, 0, False, 22),     # 800 tiles on 768 slots: blocks walk two tiles; no act
-    (2, 80, 80, 64, 64, 3, 1, 1, True, 23),
-    (2, 72, 56, 64, 64, 3, 1, 1, True, 23),         # partial spatial tiles
-    (1, 80, 80, 128, 96, 3, 1, 0, False, 23),       # two channel tiles, the second half full (96 = 64 + 32)
-    (6, 160, 160, 64, 64, 3, 1, 1, False, 23),      # 600 tiles on 512 slots
-    (2, 32, 32, 128, 128, 3, 1, 1, True, 24),
-    (3, 48, 32, 192, 256, 3, 1, 0, False, 24),
-    (2, 40, 40, 256, 64, 3, 1, 1, False, 21),       # by shape: Cout <= 64 -> 64-channel block
     # slab kernel for narrow maps (25): R full-width rows x 64 channels, linear pixel groups
     (2, 20, 20, 256, 256, 3, 1, 1, True, 25),       # the 20x20 C2f layers: two slabs of 10 rows, 12.5 groups
     (3, 20, 20, 512, 224, 3, 1, 0, False, 25),      # fused head-level convs: ragged channel tile (224 = 3 x 64 + 32)

@@ -30,23 +30,63 @@ def test_predict_like_yolo8_seg_predict(tmp_path, cuda_device):
     assert res.orig_shape == (320, 320) and res.names == {0: "defect"}
     assert os.path.isfile(os.path.join(res.save_dir, "787-225_01_Ch-0_51.jpg"))
     assert res.masks is not None and res.masks.data.shape[1:] == (640, 640)
-    # oracle end to end on the same image / weights
+    # ---- oracle end to end on the same image / weights, compared with SURVEY 8d's margin rule (tests/keepset.py): the keep
+    # set and its order are EXACT except detections the rule explains (each one printed); margins are the stated ones
+    # (2e-3 on the score, 1e-3 on the IoU) or, where larger, 1.25 x what fp16 storage itself costs on this image (the
+    # engine-format oracle against the fp32 oracle, measured here)
+    import engine_format_oracle as efo
+    from keepset import _iou, _xyxy, anchors_of, common_order_ok, compare_keepsets
     omodel = orc.SegmentationModel("n", 1)
     omodel.load_state_dict(sd)
     img = load_image(png)[:, :, ::-1]
     ref = orc.predict(omodel, [np.ascontiguousarray(img)], 640, 0.25, 0.7, 300)[0]
+    lb = orc.letterbox(np.ascontiguousarray(img), (640, 640))[0]
+    x = orc.preprocess([lb])
+    fmodel = orc.SegmentationModel("n", 1)
+    fmodel.load_state_dict(sd)
+    fmodel = efo.to_engine_format(fmodel.eval())
+    with torch.no_grad():
+        o_preds = omodel(x)[0].permute(0, 2, 1)[0].contiguous().numpy()          # (8400, 37)
+        f_preds = fmodel(x)[0].permute(0, 2, 1)[0].contiguous().numpy()
+    eng = model._engines[(640, 640, 0)]                                          # the engine predict() just used
+    xg = torch.from_numpy(np.ascontiguousarray(lb[None, :, :, ::-1])).to(cuda_device)   # BGR -> RGB as predict() does
+    g_preds_t, g_protos = eng.forward(xg)
+    g_dets, g_counts, _ = eng.postprocess(g_preds_t, g_protos, 0.25, 0.7, 300, masks=False)
+    torch.cuda.synchronize()
+    g_preds, n_g = g_preds_t[0].cpu().numpy(), int(g_counts[0])
     got = res.boxes.data.numpy()
-    # margin rule: detections whose score is within 2e-3 of conf may differ; the rest must match
-    strong_ref = ref["boxes"][ref["boxes"][:, 4] > 0.25 + 2e-3]
-    strong_got = got[got[:, 4] > 0.25 + 2e-3]
-    assert abs(len(strong_ref) - len(strong_got)) <= 1
-    n = min(len(strong_ref), len(strong_got), 5)
-    assert n > 0, "synthetic weights with cls_bias=-2 must detect something on the fixture"
-    assert np.abs(strong_got[:n, :4] - strong_ref[:n, :4]).max() <= 1.0      # original-image pixels
-    assert np.abs(strong_got[:n, 4] - strong_ref[:n, 4]).max() <= 5e-3
-    assert np.array_equal(strong_got[:n, 5], strong_ref[:n, 5])              # class indices exact
-    agree = (res.masks.data.numpy()[:n].astype(bool) == ref["masks"][:n]).mean()
-    assert agree >= 0.995
+    assert n_g == len(got) and np.array_equal(got[:, 4:6], g_dets[0, :n_g, 4:6].cpu().numpy())   # predict() = this forward + NMS
+    f_sc = float(np.abs(f_preds[:, 4] - o_preds[:, 4]).max())
+    f_box = float(np.abs(f_preds[:, :4] - o_preds[:, :4]).max())
+    cand = np.nonzero(o_preds[:, 4] > 0.2)[0][:300]
+    bo, bf = _xyxy(o_preds), _xyxy(f_preds)
+    f_iou = max([abs(_iou(bo[i], bo[j]) - _iou(bf[i], bf[j])) for ii, i in enumerate(cand) for j in cand[ii + 1:]
+                 if _iou(bo[i], bo[j]) > 0.4] or [0.0])
+    m_conf, m_iou = max(2e-3, 1.25 * f_sc), max(1e-3, 1.25 * f_iou)
+    kg = anchors_of(g_dets[0, :n_g].cpu().numpy(), g_preds)
+    kr = anchors_of(ref["det_letterboxed"], o_preds)
+    exc, bad = compare_keepsets(kg, g_preds, kr, o_preds, 0.25, 0.7, m_conf, m_iou)
+    for side, a, why in exc:
+        print(f"  excepted: anchor {a} kept by {'HIP' if side == 'a' else 'oracle'} only, rule '{why}': score HIP {g_preds[a, 4]:.5f} "
+              f"oracle {o_preds[a, 4]:.5f}")
+    print(f"{len(kr)} oracle detections, {len(kg)} HIP; {len(exc)} excepted, {len(bad)} unexplained (m_conf {m_conf:.2e}, m_iou {m_iou:.2e}; "
+          f"format floor score {f_sc:.2e} box {f_box:.3f} px)")
+    assert not bad, bad
+    assert len(kr) > 0, "synthetic weights with cls_bias=-2 must detect something on the fixture"
+    assert len(exc) <= max(2, len(kr) // 10)
+    assert common_order_ok(kg, kr, o_preds[:, 4], m_conf)
+    # the detections both sides keep: class index exact, score / box within the stated tolerance or 1.5 x the format floor,
+    # masks >= 99.5 % (boxes in ORIGINAL pixels: the 320 px image is letterboxed x2, so 0.5 network px = 0.25 px here)
+    row_g = {a: i for i, a in enumerate(kg)}
+    row_r = {a: i for i, a in enumerate(kr)}
+    common = [a for a in kg if a in row_r]
+    assert len(common) >= max(1, len(kr) - len(exc))
+    gi, ri = [row_g[a] for a in common], [row_r[a] for a in common]
+    assert np.array_equal(got[gi, 5], ref["boxes"][ri, 5])
+    assert np.abs(got[gi, 4] - ref["boxes"][ri, 4]).max() <= max(2e-3, 1.5 * f_sc)
+    assert np.abs(got[gi, :4] - ref["boxes"][ri, :4]).max() <= max(0.5, 1.5 * f_box) / 2.0
+    agree = (res.masks.data.numpy()[gi].astype(bool) == ref["masks"][ri]).mean()
+    assert agree >= 0.995, agree
     # folder-eval style usage (yolo/yolo_folder_eval.py:16-29)
     for r in model.predict(os.path.join(GOLDEN, "bscans"), verbose=False):
         for box in r.boxes:

@@ -66,7 +66,7 @@ def test_forward_and_postprocess_parity(scale, nc, shape, batch, cuda_device):
           f"rms {floor['sc_rms']:.2e}, box max {floor['box']:.3f} rms {floor['box_rms']:.4f} px")
     # SURVEY 8d's 2e-3 for 99 % of the scores, unless the format itself is already beyond it on this (deeper) network
     assert e_pr <= 1e-2 and e_mc <= 1e-2 and e_box <= 0.5 and p99 <= max(2e-3, 1.5 * floor['sc_p99'])
-    assert got["sc"] <= 2 * floor["sc"] and got["box"] <= 2 * floor["box"]
+    assert got["sc"] <= 1.5 * floor["sc"] and got["box"] <= 1.5 * floor["box"]
     assert got["sc_rms"] <= 1.25 * floor["sc_rms"] + 1e-5 and got["box_rms"] <= 1.25 * floor["box_rms"] + 1e-3
     # NMS (+ multi-class offsets) bit-exact on identical preds; masks >= 99.5 %
     for conf, iou, max_det in ((0.25, 0.7, 300), (0.05, 0.5, 20)):
