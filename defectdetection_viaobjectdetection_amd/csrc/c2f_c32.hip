@@ -1,0 +1,551 @@
+// A whole C2f block body with 32 hidden channels as ONE kernel (YOLOv8s-seg model.2 at 160 x 160):
+//     t   = SiLU(conv3x3(y1) + bA)            Bottleneck.cv1
+//     y2  = y1 + SiLU(conv3x3(t) + bB)        Bottleneck.cv2 (+ shortcut)
+//     out = SiLU(Wc . [y0, y1, y2] + bC)      C2f.cv2 (1x1, 96 -> 64)
+// NHWC fp16, v_mfma_f32_32x32x16_f16 (gfx950).  [y0, y1] = the 64 channels C2f.cv1 wrote (the stem + model.1 + cv1 launch).
+//
+// Replaces: C2f / Bottleneck of upstream's nn.modules.block, reached through
+// /root/reference/BscanBased/yolo8_seg_predict.py:8 (model.predict) -- three Conv+BN+SiLU launches and two HBM round trips.
+//
+// Why its own kernel ("C <= 64 layers are HBM-bound unless bottleneck-fused").  At batch 32 the three
+// launches moved 105 MB x (1 + 1 + 1 + 1 + 1 + 3 + 2) = 1.05 GB for 44 GFLOP and took 34 + 44 + 61 us; fused, the block
+// reads its 64 input channels once and writes its 64 output channels once (210 MB): t and y2 never exist in HBM.
+//
+// Structure.  One persistent block per CU, 8 waves in TWO TEAMS that work on different tiles at the same time:
+//   team X (waves 0-3) computes t of tile i+1 (the 10 x 18-pixel halo region of an 8 x 16 tile: five 32-pixel MFMA blocks of
+//          two rows x 16 columns + one block for columns 16-17) from the y1 patch and writes it to LDS as fp16;
+//   team Y (waves 4-7, wave q owns tile rows 2q, 2q+1) computes y2 of tile i from t (LDS), keeps it IN REGISTERS -- the
+//          rows of Wb are permuted so that the accumulator of lane (pixel, half) is exactly the B operand of the 1x1
+//          stage -- and runs the 1x1 over [y0, y1] (patch in LDS) and y2 (registers), then stores.
+// A SIMD hosts one wave of each team, so the MFMA-heavy phase of one runs beside the SiLU epilogue of the other; there is
+// ONE s_barrier per tile.  All weights live in REGISTERS (X: 72 VGPRs of Wa; Y: 72 of Wb + 48 of Wc): no weight traffic
+// through LDS at all, the LDS array only serves the activation fragments (one ds_read_b128 per MFMA).  The patch of tile
+// i+2 streams in by LDS-DMA (buffer loads; out-of-image pixels are out-of-range offsets = zero fill) under tile i.
+//
+// LDS images: 64-byte rows (one pixel x 32 channels), pitch 20 pixels (a multiple of 4), 16-byte chunk index XOR-ed with
+// (column >> 2) & 3 on the DMA source side, on the t writes and on every read: the 16 lanes of a ds_read_b128 service
+// group cover columns {0-3, 12-15} of one row and {4-11} of the next (shifted by the tap), which then hit 16 distinct
+// 16-byte bank groups.
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <type_traits>
+
+#include "common.h"
+
+namespace m355 {
+namespace {
+
+typedef float float16v __attribute__((ext_vector_type(16)));
+
+constexpr int TH = 8, TW = 16, PP = 20;          // output tile, pixel pitch of the y1 patch and of t
+constexpr int Y1_BYTES = 12 * PP * 64;           // 15360: 12 x 20 patch of y1 (halo 2)
+constexpr int Y0_BYTES = TH * TW * 64;           // 8192: the tile's own pixels of y0
+constexpr int PATCH_BYTES = Y1_BYTES + Y0_BYTES; // 23552
+constexpr int NPIECES = PATCH_BYTES / 1024;      // 23 DMA pieces of 16 rows
+constexpr int NWAVES = 8;
+constexpr int P_IT = 12;                         // DMA pieces per loader wave (wave 2: pieces 0-11, wave 3: 12-22)
+constexpr int NBUF = 4;                          // patch buffers: tile i (Y), i+1 (X), i+2 (landing), i+3 (being issued)
+constexpr int T_BYTES = 10 * PP * 64;            // 12800: the 10 x 18 region of t at pitch 20
+constexpr int T_OFF = NBUF * PATCH_BYTES;
+constexpr int BIAS_OFF = T_OFF + 2 * T_BYTES;    // 32 + 32 + 64 floats
+constexpr int WC_OFF = BIAS_OFF + 512;           // Wc in MFMA fragment order: [channel block][K slice][lane] x 16 bytes
+constexpr int STG_OFF = WC_OFF + 12 * 1024;     // output staging: 4 waves x 32 pixels x 128 bytes
+constexpr int LDS_BYTES = STG_OFF + 4 * 4096;    // 148992
+
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// MFMA row rho = 8 q + 4 h + i is accumulator register 4 q + i of lane-half h.
+// Plain order: lane-half h's 16 registers are 16 consecutive channels 16 h + r (what a 16-byte NHWC store wants).
+__device__ __forceinline__ int row_plain(int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); }
+// Operand order: register r of lane-half h is channel 16 (r >> 3) + 8 h + (r & 7), so that registers 8 s .. 8 s + 7,
+// converted to fp16, ARE the B fragment (K slice s, k = 16 s + 8 h + j) of the next 32x32x16 MFMA for the same pixels.
+__device__ __forceinline__ int row_operand(int rho) {
+  const int q = rho >> 3, h = (rho >> 2) & 1, i = rho & 3;
+  return 16 * (q >> 1) + 8 * h + 4 * (q & 1) + i;
+}
+
+// SiLU of all 16 accumulators of a lane, STAGED: sixteen multiplies, sixteen v_exp, sixteen adds, sixteen v_rcp, sixteen
+// multiplies -- the same five operations per element as m355_silu (same bits), but every result is used sixteen
+// instructions after it was issued.  Left to itself the compiler interleaves two elements at a time and each
+// transcendental's consumer waits for it: measured 44 cycles per element (89 beside the partner wave's MFMAs) against
+// 28 of issue.
+__device__ __forceinline__ void silu16(float16v& v) {
+#pragma clang fp contract(off)
+  float16v t;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) t[j] = v[j] * -1.4426950408889634f;
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) t[j] = __builtin_amdgcn_exp2f(t[j]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) t[j] = 1.0f + t[j];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) t[j] = __builtin_amdgcn_rcpf(t[j]);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = v[j] * t[j];
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ half8 to_half8(const float16v& v, int lo) {
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = m355_to_half(v[lo + j]);
+  return o;
+}
+
+__global__ __launch_bounds__(512, 2) void c2f_c32_kernel(const C2fC32Args a, int tiles_x, int tiles_y, int ntiles, int sx, int sy, int sb,
+                                                        unsigned long long* stamps, int prio) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = a.H, W = a.W, nwg = gridDim.x;
+  const int n = lane & 31, h = lane >> 5;
+  // diagnostic builds of a launch only (M355_C2F_STAMPS): cycles per section and wave
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
+#define C2F_STAMP(k)                                                                                      \
+  if (stamps) {                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    const unsigned long long tn = __builtin_amdgcn_s_memtime();                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    tacc[k] += tn - tlast;                                                                                \
+    tlast = tn;                                                                                           \
+  }
+  auto stamps_out = [&]() __attribute__((always_inline)) {
+    if (stamps && lane == 0) {
+      unsigned long long* o = stamps + ((long)blockIdx.x * NWAVES + wave) * 8;
+      for (int k = 0; k < 8; ++k) o[k] = tacc[k];
+    }
+  };
+
+  if (tid < 32) ((float*)(smem + BIAS_OFF))[tid] = a.ba[tid];
+  else if (tid < 64) ((float*)(smem + BIAS_OFF))[tid] = a.bb[tid - 32];
+  else if (tid < 128) ((float*)(smem + BIAS_OFF))[tid] = a.bc[tid - 64];
+  for (int i = tid; i < 12 * 64; i += 64 * NWAVES) {     // Wc -> LDS, fragment order (read back linearly: conflict free)
+    const int f = i >> 6, l = i & 63, mb = f / 6, sl = f - 6 * mb;
+    *(float4v*)(smem + WC_OFF + i * 16) = *(const float4v*)(a.wc + (long)(32 * mb + row_plain(l & 31)) * a.kpad_c + 16 * sl + 8 * (l >> 5));
+  }
+
+  // ---- tile walk (static, XCD-aware: the virtual blocks of one XCD cover a contiguous run of tiles).  Virtual block
+  // vb = blockIdx.x + k * gridDim.x stays in XCD group vb & 7 and its linear tile index advances by gridDim.x / 8 per step:
+  // the coordinates are stepped with carries ((sx, sy, sb) = that stride in tile columns / rows / images, from the host),
+  // no division in the loop.
+  auto decode = [&](int vb, int& tb, int& ty, int& tx) __attribute__((always_inline)) {
+    const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+    const int L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+    tx = L % tiles_x;
+    const int rest = L / tiles_x;
+    tb = rest / tiles_y;
+    ty = rest - tb * tiles_y;
+  };
+  auto step_tile = [&](int& tb, int& ty, int& tx) __attribute__((always_inline)) {
+    tx += sx;
+    if (tx >= tiles_x) { tx -= tiles_x; ++ty; }
+    ty += sy;
+    if (ty >= tiles_y) { ty -= tiles_y; ++tb; }
+    tb += sb;
+  };
+  // Iteration `it` (from -1): the loader waves issue the patch of tile it + 3, team X computes t of tile it + 1, team Y
+  // finishes tile it (nothing at it = -1) after the deferred output epilogue of tile it - 1; one barrier; the block leaves
+  // when tile it + 1 does not exist.  Slot k of tbi / ty0 / tx0 / have = tile it + k of this block's walk.
+  int tbi[4], ty0[4], tx0[4];
+  bool have[4];
+  int nb_, nty, ntx;                                // tile coordinates (tile units) of the newest stepped tile
+  int vbn = blockIdx.x + nwg;                       // virtual block of the next tile to step to
+  decode(blockIdx.x, nb_, nty, ntx);
+  have[1] = true;                                   // tile 0 exists: the grid is never larger than the tile count
+  tbi[1] = nb_; ty0[1] = nty * TH; tx0[1] = ntx * TW;
+  auto plan = [&](int k) __attribute__((always_inline)) {      // slot k <- the next tile of the walk, if there is one
+    have[k] = have[k - 1] && vbn < ntiles;
+    if (have[k]) {
+      step_tile(nb_, nty, ntx);
+      tbi[k] = nb_; ty0[k] = nty * TH; tx0[k] = ntx * TW;
+      vbn += nwg;
+    }
+  };
+  plan(2);
+  auto advance = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { tbi[k] = tbi[k + 1]; ty0[k] = ty0[k + 1]; tx0[k] = tx0[k + 1]; have[k] = have[k + 1]; }
+  };
+
+  if (wave < 4) {
+    // =====================================================================================================
+    // team X: t = SiLU(conv3x3(y1) + bA) on the halo region of the NEXT tile.  Waves 0 / 1: two pixel blocks each
+    // (b0 = wave: rows 2 b0, 2 b0 + 1 x columns 0-15; wave 0 also block 4 = rows 8, 9; wave 1 block 5 = columns 16, 17 x rows
+    // 0-9: lanes 0-19 of each half, the others compute a clamped pixel and store nothing).  Waves 2 / 3: one block each AND
+    // the LDS-DMA of every patch (measured: a piece costs the issuing wave 60-180 cycles; spread over all eight waves the
+    // three pieces per wave cost team Y, the critical path, 1 000 cycles per tile beside its partner's MFMAs).
+    // =====================================================================================================
+    auto team_x = [&](auto nbc) __attribute__((always_inline)) {
+      constexpr int NB = decltype(nbc)::value;
+      constexpr bool LOADER = NB == 1;
+      half8 wa[18];
+      {
+        const half_t* wp = a.wa + (long)row_plain(n) * a.kpad_a + 8 * h;
+#pragma unroll
+        for (int s = 0; s < 18; ++s) wa[s] = *(const half8*)(wp + 16 * s);
+      }
+      // ---- loader state: pieces g = g0 + i (16 LDS rows each); lane = (row 16 g + lane / 4, chunk slot lane % 4).
+      // Pieces 0-14: the y1 patch (12 x 20 pixels from (y0 - 2, x0 - 2), channels 32-63); 15-22: y0 of the tile's own pixels.
+      const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)a.x, 0, (int)((a.B - 1) * a.x_bstride + (long)H * W * a.ldx) * 2, 0x00020000);
+      const int img_stride = (int)a.x_bstride * 2;
+      const int g0 = (wave - 2) * P_IT;
+      int prel[LOADER ? P_IT : 1], prc[LOADER ? P_IT : 1];
+      if (LOADER) {
+#pragma unroll
+        for (int i = 0; i < P_IT; ++i) {
+          const int g = g0 + i;
+          const int slot = lane & 3;
+          if (g < 15) {
+            const int R = 16 * g + (lane >> 2);
+            const int pr = R / PP, pc = R - pr * PP;
+            const int cc = slot ^ ((pc >> 2) & 3);
+            prel[i] = ((pr * W + pc) * a.ldx + 32 + cc * 8) * 2;
+            prc[i] = pr | (pc << 8);
+          } else {
+            const int R = 16 * (g - 15) + (lane >> 2);
+            const int r = R >> 4, c = R & 15;
+            const int cc = slot ^ ((c >> 2) & 3);
+            prel[i] = (((r + 2) * W + (c + 2)) * a.ldx + cc * 8) * 2;
+            prc[i] = (r + 2) | ((c + 2) << 8);
+          }
+        }
+      }
+      auto issue_patch = [&](int tb, int y0, int x0, int buf) __attribute__((always_inline)) {
+        if (!LOADER) return;
+        const int origin = (((y0 - 2) * W + (x0 - 2)) * a.ldx) * 2;   // may be negative for border tiles: those lanes are masked
+        char* const dst = smem + buf * PATCH_BYTES + g0 * 1024;
+        const int soff = tb * img_stride;
+        if (y0 >= 2 && y0 + TH + 2 <= H && x0 >= 2 && x0 + TW + 2 <= W) {   // interior tile: every patch pixel is in the image
+#pragma unroll
+          for (int i = 0; i < P_IT; ++i)
+            if (g0 + i < NPIECES) dma16(rs_x, origin + prel[i], soff, dst + i * 1024);
+        } else {
+#pragma unroll
+          for (int i = 0; i < P_IT; ++i) {
+            if (g0 + i < NPIECES) {
+              const int yy = y0 - 2 + (prc[i] & 255), xx = x0 - 2 + (prc[i] >> 8);
+              const bool ok = (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+              dma16(rs_x, ok ? origin + prel[i] : (int)0x80000000, soff, dst + i * 1024);   // out of range = zero fill
+            }
+          }
+        }
+      };
+      int ti[NB], tj[NB];
+      ti[0] = 2 * wave + (n >> 4); tj[0] = n & 15;
+      if (NB == 2) {
+        if (wave == 0) { ti[NB - 1] = 8 + (n >> 4); tj[NB - 1] = n & 15; }
+        else { ti[NB - 1] = (n >> 1) < 10 ? (n >> 1) : 9; tj[NB - 1] = 16 + (n & 1); }
+      }
+      const bool store1 = wave == 0 || n < 20;
+      int offa[NB][3][2], twr[NB][2];
+#pragma unroll
+      for (int k = 0; k < NB; ++k) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int col = tj[k] + kw;
+#pragma unroll
+          for (int s = 0; s < 2; ++s) offa[k][kw][s] = (ti[k] * PP + col) * 64 + (((2 * s + h) ^ ((col >> 2) & 3)) << 4);
+        }
+        const int sw = (tj[k] >> 2) & 3;
+        twr[k][0] = (ti[k] * PP + tj[k]) * 64 + (((2 * h) ^ sw) << 4);
+        twr[k][1] = (ti[k] * PP + tj[k]) * 64 + (((2 * h + 1) ^ sw) << 4);
+      }
+      issue_patch(tbi[1], ty0[1], tx0[1], 0);
+      if (have[2]) issue_patch(tbi[2], ty0[2], tx0[2], 1);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                          // patches 0 and 1 landed, biases and Wc visible
+      if (stamps) tlast = __builtin_amdgcn_s_memtime();
+      for (int it = -1;; ++it) {
+        plan(3);
+        // the K loop runs in rows of three taps: the fragments of row kh + 1 are read under the MFMAs of row kh (the
+        // compiler's own order kept ONE read ahead of each MFMA: 60-75 cycles per 32-cycle MFMA)
+        half8 fr[2][6 * NB];
+        const char* const pb = smem + ((it + 1) & (NBUF - 1)) * PATCH_BYTES;
+        auto read_row = [&](int kh, int set) __attribute__((always_inline)) {
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+              for (int k = 0; k < NB; ++k) fr[set][(kw * 2 + s) * NB + k] = *(const half8*)(pb + offa[k][kw][s] + kh * PP * 64);
+        };
+        if (have[1]) read_row(0, 0);
+        const bool issued = LOADER && have[3];
+        if (issued) issue_patch(tbi[3], ty0[3], tx0[3], (it + 3) & (NBUF - 1));
+        C2F_STAMP(0)   // tile step + DMA issue
+        if (have[1]) {
+          char* const tbuf = smem + T_OFF + ((it + 1) & 1) * T_BYTES;
+          float16v acc[NB];
+          {
+            float16v v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float4v u = *(const float4v*)(smem + BIAS_OFF + (16 * h + 4 * q) * 4);
+              v[q * 4 + 0] = u[0]; v[q * 4 + 1] = u[1]; v[q * 4 + 2] = u[2]; v[q * 4 + 3] = u[3];
+            }
+#pragma unroll
+            for (int k = 0; k < NB; ++k) acc[k] = v;
+          }
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            if (kh < 2) read_row(kh + 1, (kh + 1) & 1);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+              for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int k = 0; k < NB; ++k)
+                  acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[2 * (3 * kh + kw) + s], fr[kh & 1][(kw * 2 + s) * NB + k], acc[k], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          C2F_STAMP(1)   // reads + MFMAs
+          // t outside the image is the ZERO PADDING of the second conv, not the first conv evaluated on padding
+#pragma unroll
+          for (int k = 0; k < NB; ++k) {
+            const bool in = (unsigned)(ty0[1] - 1 + ti[k]) < (unsigned)H && (unsigned)(tx0[1] - 1 + tj[k]) < (unsigned)W;
+            silu16(acc[k]);
+            half8 lo = to_half8(acc[k], 0), hi = to_half8(acc[k], 8);
+            if (!in) { lo = (half8)(half_t)0.f; hi = lo; }
+            if (k == 0 || store1) {
+              *(half8*)(tbuf + twr[k][0]) = lo;
+              *(half8*)(tbuf + twr[k][1]) = hi;
+            }
+          }
+        }
+        C2F_STAMP(2)   // SiLU + t writes
+        // the patch of tile it + 2 (issued one iteration ago) has landed: everything but this iteration's pieces
+        if (!issued) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else if (wave == 2) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(11) lgkmcnt(0)" ::: "memory");
+        C2F_STAMP(3)   // own DMA landed
+        __builtin_amdgcn_s_barrier();
+        C2F_STAMP(4)   // barrier
+        if (!have[1]) break;
+        advance();
+      }
+      stamps_out();
+    };
+    if (wave < 2) team_x(std::integral_constant<int, 2>{});
+    else team_x(std::integral_constant<int, 1>{});
+  } else {
+    // =====================================================================================================
+    // team Y: y2 = y1 + SiLU(conv3x3(t) + bB) in registers, out = SiLU(Wc . [y0, y1, y2] + bC), store
+    // =====================================================================================================
+    const int q = wave - 4;
+    half8 wb[18];
+    {
+      const half_t* wp = a.wb + (long)row_operand(n) * a.kpad_b + 8 * h;
+#pragma unroll
+      for (int s = 0; s < 18; ++s) wb[s] = *(const half8*)(wp + 16 * s);
+    }
+    auto wcf = [&](int mb, int sl) __attribute__((always_inline)) {      // Wc fragment (channel block, K slice) from LDS
+      return *(const half8*)(smem + WC_OFF + ((mb * 6 + sl) * 64 + lane) * 16);
+    };
+    const int r = 2 * q + (n >> 4), c = n & 15;
+    int offb[3][2], offy1[2], offy0[2];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) {
+      const int col = c + kw;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) offb[kw][s] = (r * PP + col) * 64 + (((2 * s + h) ^ ((col >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      offy1[s] = ((r + 2) * PP + c + 2) * 64 + (((2 * s + h) ^ (((c + 2) >> 2) & 3)) << 4);   // y1 of this pixel, channels 16 s + 8 h ..
+      offy0[s] = Y1_BYTES + (r * TW + c) * 64 + (((2 * s + h) ^ ((c >> 2) & 3)) << 4);
+    }
+    auto bias_vec = [&](int off0, int off1) __attribute__((always_inline)) {   // registers 0-7 from off0, 8-15 from off1 (floats)
+      float16v v;
+      const float4v u0 = *(const float4v*)(smem + BIAS_OFF + off0 * 4), u1 = *(const float4v*)(smem + BIAS_OFF + off0 * 4 + 16);
+      const float4v u2 = *(const float4v*)(smem + BIAS_OFF + off1 * 4), u3 = *(const float4v*)(smem + BIAS_OFF + off1 * 4 + 16);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { v[j] = u0[j]; v[4 + j] = u1[j]; v[8 + j] = u2[j]; v[12 + j] = u3[j]; }
+      return v;
+    };
+    // The output epilogue of a tile (32 SiLUs per lane + four stores) is DEFERRED into the next iteration: it then runs
+    // while the partner wave of team X on this SIMD is in its MFMA phase, and this wave's MFMAs run beside X's epilogue.
+    float16v o0, o1;
+    // Stores.  In the accumulator layout a lane holds 16-byte pieces of ONE pixel: a store instruction would scatter 64
+    // pieces over 32 different 128-byte lines, and such row-per-lane stores are issue-bound (measured here: ~360 cycles per
+    // instruction, 1 440 of the 2 850 cycles of this epilogue).  The wave transposes its own 32 pixels x 64 channels through
+    // 4 KB of LDS (no barrier: nobody else touches the region) and stores 1 KiB contiguous per instruction: eight whole
+    // 128-byte pixel rows.  16-byte chunk index XOR (pixel & 7): both the 8-lane write groups and the 16-lane read groups
+    // hit distinct banks.
+    char* const stg = smem + STG_OFF + q * 4096;
+    const int st_w = n * 128, st_sw = n & 7;                  // write side: this lane's pixel row
+    const int st_p = lane >> 3, st_k = lane & 7;              // read side: pixel 8 i + st_p, chunk st_k
+    int out_off = 0;                                          // element offset of this wave's first pixel row pair in y
+    auto flush = [&]() __attribute__((always_inline)) {   // lane (pixel, half) holds channels 32 mb + 16 h + (0 .. 15)
+      silu16(o0);
+      *(half8*)(stg + st_w + (((2 * h) ^ st_sw) << 4)) = to_half8(o0, 0);
+      *(half8*)(stg + st_w + (((2 * h + 1) ^ st_sw) << 4)) = to_half8(o0, 8);
+      silu16(o1);
+      *(half8*)(stg + st_w + (((4 + 2 * h) ^ st_sw) << 4)) = to_half8(o1, 0);
+      *(half8*)(stg + st_w + (((5 + 2 * h) ^ st_sw) << 4)) = to_half8(o1, 8);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      half8 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int p = 8 * i + st_p;
+        v[i] = *(const half8*)(stg + p * 128 + ((st_k ^ (p & 7)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)      // pixels 8 i .. 8 i + 7 of the block: row 2 q + (i >> 1), columns 8 (i & 1) ..
+        *(half8*)(a.y + out_off + ((long)(i >> 1) * W + 8 * (i & 1) + st_p) * a.ldy + st_k * 8) = v[i];
+    };
+
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                          // patches 0 and 1 landed, biases and Wc visible
+    // team Y is the critical path (48 of a SIMD's 64-80 SiLU groups per tile): it wins the issue arbitration against its
+    // partner wave of team X, which has the slack (M355_C2F_NOPRIO=1 in the launcher turns this off for A/B runs)
+    if (prio) __builtin_amdgcn_s_setprio(1);
+    if (stamps) tlast = __builtin_amdgcn_s_memtime();
+    for (int it = -1;; ++it) {
+      plan(3);
+      C2F_STAMP(0)   // tile step
+      const char* const pb = smem + (it & (NBUF - 1)) * PATCH_BYTES;
+      const char* const tb_ = smem + T_OFF + (it & 1) * T_BYTES;
+      half8 fr[2][6], f0[2], f1[2];
+      auto read_row = [&](int kh, int set) __attribute__((always_inline)) {
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+          for (int s = 0; s < 2; ++s) fr[set][kw * 2 + s] = *(const half8*)(tb_ + offb[kw][s] + kh * PP * 64);
+      };
+      if (it >= 0) {                                       // this tile's first fragments land under the deferred epilogue
+        read_row(0, 0);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) { f0[s] = *(const half8*)(pb + offy0[s]); f1[s] = *(const half8*)(pb + offy1[s]); }
+      }
+      if (it >= 1) flush();                                // tile it - 1
+      C2F_STAMP(1)   // deferred output epilogue + stores
+      if (it >= 0) {
+        // ---- Bottleneck.cv2: 18 K slices over t, rows of three taps
+        float16v acc = bias_vec(32 + 8 * h, 32 + 16 + 8 * h);
+        half8 wq[2][4];                                    // Wc fragments of the next four 1x1 MFMAs
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          if (kh < 2) read_row(kh + 1, (kh + 1) & 1);
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wq[0][j] = wcf(j & 1, j >> 1);      // (mb, slice): slices 0, 1 = y0
+          }
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wb[2 * (3 * kh + kw) + s], fr[kh & 1][kw * 2 + s], acc, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        C2F_STAMP(2)   // Bottleneck.cv2 reads + MFMAs
+        // ---- C2f.cv2 over [y0, y1]
+        o0 = bias_vec(64 + 16 * h, 64 + 16 * h + 8);
+        o1 = bias_vec(96 + 16 * h, 96 + 16 * h + 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[1][j] = wcf(j & 1, 2 + (j >> 1));    // slices 2, 3 = y1
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][0], f0[0], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][1], f0[0], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][2], f0[1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][3], f0[1], o1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wq[0][j] = wcf(j & 1, 4 + (j >> 1));    // slices 4, 5 = y2: land under the y2 epilogue
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[1][0], f1[0], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[1][1], f1[0], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[1][2], f1[1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[1][3], f1[1], o1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        C2F_STAMP(3)   // 1x1 over y0, y1
+        // ---- y2 = y1 + SiLU(.) -> fp16 (the rounding point of the unfused path's HBM store): B fragments of slices 4, 5
+        half8 y2[2];
+        silu16(acc);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {                      // channels 16 s + 8 h .. + 7 = registers 8 s .. 8 s + 7
+            float v = acc[8 * s + j];
+            if (a.shortcut) {
+#pragma clang fp contract(off)
+              v = v + (float)f1[s][j];
+            }
+            y2[s][j] = m355_to_half(v);
+          }
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][0], y2[0], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][1], y2[0], o1, 0, 0, 0);
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][2], y2[1], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][3], y2[1], o1, 0, 0, 0);
+        C2F_STAMP(4)   // y2 epilogue + the last four MFMAs
+        out_off = (int)((long)tbi[0] * a.y_bstride + ((long)(ty0[0] + 2 * q) * W + tx0[0]) * a.ldy);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this team issues no loads: its stores stay in flight)
+      C2F_STAMP(5)
+      __builtin_amdgcn_s_barrier();
+      C2F_STAMP(6)   // barrier
+      if (!have[1]) break;
+      advance();
+    }
+    flush();                                               // the block's last tile
+    stamps_out();
+  }
+#undef C2F_STAMP
+}
+
+}  // namespace
+
+// Eligibility: map a multiple of the 8 x 16 tile, 16-byte aligned pixel rows, the buffers inside 31-bit byte offsets.
+bool c2f_c32_ok(const C2fC32Args& a) {
+  if (!a.x || !a.y || !a.wa || !a.wb || !a.wc || !a.ba || !a.bb || !a.bc) return false;
+  if (a.H % TH || a.W % TW || a.ldx % 8 || a.ldy % 8 || a.ldx < 64 || a.ldy < 64 || a.B < 1) return false;
+  if (a.kpad_a < 288 || a.kpad_b < 288 || a.kpad_c < 96 || a.kpad_a % 8 || a.kpad_b % 8 || a.kpad_c % 8) return false;
+  if (((a.B - 1) * a.y_bstride + (long)a.H * a.W * a.ldy) >= (1L << 31)) return false;   // 32-bit element offsets into y
+  return ((a.B - 1) * a.x_bstride + (long)a.H * a.W * a.ldx) * 2 < (1L << 31);
+}
+
+int launch_c2f_c32(const C2fC32Args& a, hipStream_t s) {
+  if (!c2f_c32_ok(a)) return -1;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int ntiles = a.B * tiles_y * tiles_x;
+  static int slots = 0;
+  if (!slots) {
+    hipError_t e = hipFuncSetAttribute((const void*)c2f_c32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      return -2;
+    slots = cus & ~7;   // one block per CU; the XCD-aware tile order needs gridDim.x % 8 == 0 whenever a block walks > 1 tile
+    if (slots < 8) slots = 8;
+  }
+  const int grid = ntiles <= slots ? ntiles : slots;
+  const int step = grid >> 3;                         // linear tile stride of a block's walk inside its XCD group
+  const int sx = step % tiles_x, sy = (step / tiles_x) % tiles_y, sb = step / tiles_x / tiles_y;
+  // diagnostic: M355_C2F_STAMPS=<file> -> per-wave section cycles of the LAST launch, written after a stream sync [sync]
+  static const int prio = getenv("M355_C2F_NOPRIO") ? 0 : 1;
+  static const char* st_path = getenv("M355_C2F_STAMPS");
+  static unsigned long long* d_st = nullptr;
+  if (st_path && !d_st) {
+    if (hipMalloc((void**)&d_st, (size_t)slots * NWAVES * 64) != hipSuccess) return -2;
+    (void)hipMemset(d_st, 0, (size_t)slots * NWAVES * 64);
+  }
+  hipLaunchKernelGGL(c2f_c32_kernel, dim3(grid), dim3(64 * NWAVES), LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, sx, sy, sb, d_st, prio);
+  if (st_path) {
+    if (hipStreamSynchronize(s) != hipSuccess) return -2;
+    const size_t nbytes = (size_t)grid * NWAVES * 64;
+    unsigned long long* hbuf = (unsigned long long*)malloc(nbytes);
+    (void)hipMemcpy(hbuf, d_st, nbytes, hipMemcpyDeviceToHost);
+    FILE* f = fopen(st_path, "wb");
+    if (f) { fwrite(hbuf, 1, nbytes, f); fclose(f); }
+    free(hbuf);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace m355

@@ -122,6 +122,20 @@ int launch_dfine_decode(const float* dist, const float* project, const float* re
 bool conv3x3_c32_ok(const ConvArgs& a);
 int launch_conv3x3_c32(const ConvArgs& a, hipStream_t s);
 
+// A whole C2f block body with 32 hidden channels in one launch (c2f_c32.hip): t = Conv3x3(y1), y2 = y1 + Conv3x3(t),
+// out = Conv1x1([y0, y1, y2]); x holds [y0, y1] (what C2f.cv1 wrote) in its first 64 channels.
+struct C2fC32Args {
+  const half_t* x; long x_bstride; int ldx;      // NHWC fp16, channels [0, 32) = y0, [32, 64) = y1
+  int H, W, B;
+  const half_t *wa, *wb, *wc;                    // packed fp16 rows [32][kpad_a], [32][kpad_b] (K = tap * 32 + cin), [64][kpad_c] (K = y0, y1, y2)
+  int kpad_a, kpad_b, kpad_c;
+  const float *ba, *bb, *bc;                     // folded biases: 32, 32, 64 floats
+  half_t* y; long y_bstride; int ldy;            // 64 output channels
+  int shortcut;                                  // 1: y2 = y1 + ...
+};
+bool c2f_c32_ok(const C2fC32Args& a);
+int launch_c2f_c32(const C2fC32Args& a, hipStream_t s);
+
 struct StemArgs {
   const uint8_t* x; int B, H, W;     // uint8 NHWC (B,H,W,3)
   const half_t* w16;                 // [Cout][32] fp16: k = (kh*3+kw)*3+ci, rows 27..31 zero; NOT scaled by 1/255

@@ -39,11 +39,13 @@ struct ConvLayer {
   // fused group: logical convs that were merged into this physical conv (head first-layer fusion)
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_PHASE, OP_POOL, OP_UP, OP_DECODE, OP_ADOWN };
+enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_PHASE, OP_POOL, OP_UP, OP_DECODE, OP_ADOWN, OP_C2F32 };
 
 struct Op {
   OpKind kind;
   int conv = -1;       // physical conv index (phys_)
+  int conv2 = -1, conv3 = -1;   // OP_C2F32: Bottleneck.cv2 and C2f.cv2 (conv = Bottleneck.cv1); `in` = the [y0, y1] slice C2f.cv1 wrote
+  int shortcut = 0;
   Slice in, out, res;  // tensor slices
   Slice in2;           // upsample read-through: channels [0, in2.c) of `in` come from this half-resolution slice
   Slice out2;          // OP_ADOWN: second output (max-pooled half); `out` is the average-pooled half
@@ -236,6 +238,18 @@ struct Builder {
     const int c = out.c / 2;
     const int cat = tensor(H, W, (2 + n) * c);
     conv(name + ".cv1", in, Slice{cat, 0, 2 * c}, 1, 1, Slice(), up_src);
+    if (c == 32 && n == 1 && H % 8 == 0 && W % 16 == 0 && out.c == 64 && !getenv("M355_NO_C2F32")) {
+      // the whole block body in one launch (c2f_c32.hip): t and y2 never reach HBM, no tensor for either
+      const int la = logical(name + ".m.0.cv1", c, c, 3, 1, 1, 0, 1), lb = logical(name + ".m.0.cv2", c, c, 3, 1, 1, 0, 1);
+      const int lc = logical(name + ".cv2", 3 * c, out.c, 1, 1, 1, 0, 1);
+      Op op{};
+      op.kind = OP_C2F32;
+      op.conv = phys_from({la}); op.conv2 = phys_from({lb}); op.conv3 = phys_from({lc});
+      op.in = Slice{cat, 0, 2 * c}; op.out = out; op.shortcut = shortcut ? 1 : 0;
+      e->macs += (double)H * W * (2.0 * 9 * c * c + 3.0 * c * out.c);
+      e->ops.push_back(op);
+      return;
+    }
     for (int j = 0; j < n; ++j) {
       const int tmp = tensor(H, W, c);
       const Slice src{cat, (1 + j) * c, c};
@@ -680,7 +694,7 @@ void plan_sub_batches(m355_engine* e) {
   if (e->sub_batch <= 0 || getenv("M355_NO_SUBBATCH")) { e->sub_batch = 0; return; }
   int n = 0;
   for (const Op& op : e->ops) {
-    if ((op.kind != OP_STEM && op.kind != OP_CONV) || op.lane != 0 || op.record || !op.wait_ops.empty() || op.out_ext != 0) break;
+    if ((op.kind != OP_STEM && op.kind != OP_CONV && op.kind != OP_C2F32) || op.lane != 0 || op.record || !op.wait_ops.empty() || op.out_ext != 0) break;
     const Tensor& to = e->tensors[op.out.t];
     if (to.H * 8 < e->desc.in_h) break;
     ++n;
@@ -891,6 +905,16 @@ void annotate_ops(m355_engine* e) {
           snprintf(op.layer, sizeof(op.layer), "model.22.proto.upsample+cv2+cv3");
         }
         op.wbytes = (double)p.cout_pad * p.Kpad * 2;
+        break;
+      }
+      case OP_C2F32: {
+        const Tensor& t = e->tensors[op.in.t];
+        const PhysConv &pa = e->phys[op.conv], &pb = e->phys[op.conv2], &pc = e->phys[op.conv3];
+        snprintf(op.kernel, sizeof(op.kernel), "c2f_c32<8x16px>");
+        snprintf(op.layer, sizeof(op.layer), "%s+cv2+%s", e->convs[pa.logical[0]].name, e->convs[pc.logical[0]].name);
+        op.flops = 2.0 * t.H * t.W * (pa.macs_px + pb.macs_px + pc.macs_px);
+        op.bytes = (double)t.H * t.W * (op.in.c + op.out.c) * 2;
+        op.wbytes = ((double)pa.cout * pa.Kpad + (double)pb.cout * pb.Kpad + (double)pc.cout * pc.Kpad) * 2;
         break;
       }
       case OP_POOL: {
@@ -1279,6 +1303,21 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
                                     : (op.tile == TILE_SLAB ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, op.tile, s)));
         break;
       }
+      case OP_C2F32: {
+        const Tensor& ti = e->tensors[op.in.t];
+        const Tensor& to = e->tensors[op.out.t];
+        const PhysConv &pa = e->phys[op.conv], &pb = e->phys[op.conv2], &pc = e->phys[op.conv3];
+        C2fC32Args a{};
+        a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C; a.H = ti.H; a.W = ti.W; a.B = Bq;
+        a.x = ti.p + op.in.off + b0 * a.x_bstride;
+        a.wa = pa.w; a.wb = pb.w; a.wc = pc.w; a.kpad_a = pa.Kpad; a.kpad_b = pb.Kpad; a.kpad_c = pc.Kpad;
+        a.ba = pa.bias; a.bb = pb.bias; a.bc = pc.bias;
+        a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
+        a.y = to.p + op.out.off + b0 * a.y_bstride;
+        a.shortcut = op.shortcut;
+        rc = launch_c2f_c32(a, s);
+        break;
+      }
       case OP_POOL: {
         const Tensor& t = e->tensors[op.in.t];
         rc = launch_sppf_pool(t.p + op.in.off, (long)t.H * t.W * t.C, t.C, t.p + op.out.off, (long)t.H * t.W * t.C,
@@ -1515,6 +1554,41 @@ int m355_conv2d_fwd(const void* d_x, int B, int H, int W, int cin, const float* 
                     void* stream) {
   return conv_op_common(d_x, B, H, W, cin, h_w, h_bias, cout, k, stride, act, d_res, d_y, out_f32, force_tile, 0,
                         stream);
+}
+
+int m355_c2f_c32_fwd(const void* d_x, int B, int H, int W, const float* h_wa, const float* h_ba, const float* h_wb,
+                     const float* h_bb, const float* h_wc, const float* h_bc, int shortcut, void* d_y, void* stream) {
+  if (!d_x || !d_y || !h_wa || !h_ba || !h_wb || !h_bb || !h_wc || !h_bc) return set_err(M355_ERR_INVALID, "null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 16) return set_err(M355_ERR_INVALID, "H must be a multiple of 8 and W of 16");
+  hipStream_t s = (hipStream_t)stream;
+  const int kp3 = conv_kpad(32, 3), kp1 = conv_kpad(96, 1);
+  std::vector<half_t> ra((size_t)32 * kp3, (half_t)0.f), rb((size_t)32 * kp3, (half_t)0.f), rc_((size_t)64 * kp1, (half_t)0.f);
+  pack_conv_rows(h_wa, 32, 32, 3, kp3, 0, ra);
+  pack_conv_rows(h_wb, 32, 32, 3, kp3, 0, rb);
+  pack_conv_rows(h_wc, 64, 96, 1, kp1, 0, rc_);
+  std::vector<float> bias(128);
+  for (int i = 0; i < 32; ++i) { bias[i] = h_ba[i]; bias[32 + i] = h_bb[i]; }
+  for (int i = 0; i < 64; ++i) bias[64 + i] = h_bc[i];
+  half_t* dw = nullptr;
+  float* db = nullptr;
+  const size_t na = ra.size(), nb = rb.size(), ncw = rc_.size();
+  HIP_TRYG(hipMalloc((void**)&dw, (na + nb + ncw) * sizeof(half_t)));
+  HIP_TRYG(hipMalloc((void**)&db, bias.size() * sizeof(float)));
+  HIP_TRYG(hipMemcpy(dw, ra.data(), na * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(dw + na, rb.data(), nb * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(dw + na + nb, rc_.data(), ncw * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  C2fC32Args a{};
+  a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * 64; a.ldx = 64; a.H = H; a.W = W; a.B = B;
+  a.wa = dw; a.wb = dw + na; a.wc = dw + na + nb; a.kpad_a = kp3; a.kpad_b = kp3; a.kpad_c = kp1;
+  a.ba = db; a.bb = db + 32; a.bc = db + 64;
+  a.y = (half_t*)d_y; a.y_bstride = (long)H * W * 64; a.ldy = 64; a.shortcut = shortcut;
+  const int rc = launch_c2f_c32(a, s);
+  const hipError_t se = hipStreamSynchronize(s);
+  (void)hipFree(dw); (void)hipFree(db);
+  if (rc != 0) return set_err(M355_ERR_HIP, "c2f_c32 launch failed: " + std::to_string(rc));
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("c2f_c32 kernel: ") + hipGetErrorString(se));
+  return M355_OK;
 }
 
 int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const float* h_w, int cout, int k, int stride,

@@ -28,12 +28,16 @@ from typing import Dict, List, Optional
 import torch
 import torch.nn as nn
 
-from .spec import NM, REG_MAX, SCALES, _make_divisible
+from .spec import NM, REG_MAX, SCALES, V9C, _make_divisible
 
 _UP = {"Conv": "ultralytics.nn.modules.conv", "Concat": "ultralytics.nn.modules.conv",
        "C2f": "ultralytics.nn.modules.block", "Bottleneck": "ultralytics.nn.modules.block",
        "SPPF": "ultralytics.nn.modules.block", "Proto": "ultralytics.nn.modules.block", "DFL": "ultralytics.nn.modules.block",
-       "Segment": "ultralytics.nn.modules.head", "SegmentationModel": "ultralytics.nn.tasks"}
+       "Segment": "ultralytics.nn.modules.head", "SegmentationModel": "ultralytics.nn.tasks",
+       # yolov9c-seg (GELAN): the blocks /root/reference/BscanBased/yolo_seg_train.py:7 and yolo8_seg_predict.py:4 name
+       "RepConv": "ultralytics.nn.modules.conv", "RepBottleneck": "ultralytics.nn.modules.block",
+       "RepCSP": "ultralytics.nn.modules.block", "RepNCSPELAN4": "ultralytics.nn.modules.block",
+       "ADown": "ultralytics.nn.modules.block", "SPPELAN": "ultralytics.nn.modules.block"}
 
 _classes: Dict[str, type] = {}
 
@@ -74,6 +78,71 @@ def _conv(c1: int, c2: int, k: int = 1, s: int = 1) -> nn.Module:
     m.conv = nn.Conv2d(c1, c2, k, s, k // 2, bias=False)
     m.bn = nn.BatchNorm2d(c2, eps=1e-3, momentum=0.03)
     m.act = nn.SiLU(inplace=True)
+    return m
+
+
+def _conv_noact(c1: int, c2: int, k: int) -> nn.Module:
+    m = _conv(c1, c2, k, 1)
+    m.act = nn.Identity()
+    return m
+
+
+def _repconv(c1: int, c2: int) -> nn.Module:
+    """upstream's RepConv(c1, c2, 3, 1) as RepBottleneck builds it: a 3x3 and a 1x1 Conv without activation, no identity
+    branch (bn=False), SiLU after the sum."""
+    m = _cls("RepConv")()
+    m.g, m.c1, m.c2 = 1, c1, c2
+    m.act = nn.SiLU(inplace=True)
+    m.bn = None
+    m.conv1 = _conv_noact(c1, c2, 3)
+    m.conv2 = _conv_noact(c1, c2, 1)
+    return m
+
+
+def _repbottleneck(c1: int, c2: int) -> nn.Module:
+    m = _cls("RepBottleneck")()
+    m.cv1 = _repconv(c1, c2)
+    m.cv2 = _conv(c2, c2, 3, 1)
+    m.add = c1 == c2
+    return m
+
+
+def _repcsp(c1: int, c2: int, n: int = 1) -> nn.Module:
+    m = _cls("RepCSP")()
+    c_ = c2 // 2
+    m.cv1 = _conv(c1, c_, 1, 1)
+    m.cv2 = _conv(c1, c_, 1, 1)
+    m.cv3 = _conv(2 * c_, c2, 1, 1)
+    m.m = nn.Sequential(*(_repbottleneck(c_, c_) for _ in range(n)))
+    return m
+
+
+def _elan(c1: int, c2: int, c3: int, c4: int, n: int = 1) -> nn.Module:
+    m = _cls("RepNCSPELAN4")()
+    m.c = c3 // 2
+    m.cv1 = _conv(c1, c3, 1, 1)
+    m.cv2 = nn.Sequential(_repcsp(c3 // 2, c4, n), _conv(c4, c4, 3, 1))
+    m.cv3 = nn.Sequential(_repcsp(c4, c4, n), _conv(c4, c4, 3, 1))
+    m.cv4 = _conv(c3 + 2 * c4, c2, 1, 1)
+    return m
+
+
+def _adown(c1: int, c2: int) -> nn.Module:
+    m = _cls("ADown")()
+    m.c = c2 // 2
+    m.cv1 = _conv(c1 // 2, m.c, 3, 2)
+    m.cv2 = _conv(c1 // 2, m.c, 1, 1)
+    return m
+
+
+def _sppelan(c1: int, c2: int, c3: int, k: int = 5) -> nn.Module:
+    m = _cls("SPPELAN")()
+    m.c = c3
+    m.cv1 = _conv(c1, c3, 1, 1)
+    m.cv2 = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+    m.cv3 = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+    m.cv4 = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)
+    m.cv5 = _conv(4 * c3, c2, 1, 1)
     return m
 
 
@@ -146,9 +215,70 @@ def _yaml(scale: str, nc: int) -> Dict:
                      [[15, 18, 21], 1, "Segment", ["nc", 32, 256]]]}
 
 
+def _yaml_v9c(nc: int) -> Dict:
+    """yolov9c-seg.yaml (the file /root/reference/BscanBased/yolo_seg_train.py:7 names): GELAN-C backbone + head."""
+    e = "RepNCSPELAN4"
+    return {"nc": nc, "ch": 3, "yaml_file": "yolov9c-seg.yaml",
+            "backbone": [[-1, 1, "Conv", [64, 3, 2]], [-1, 1, "Conv", [128, 3, 2]], [-1, 1, e, [256, 128, 64, 1]],
+                         [-1, 1, "ADown", [256]], [-1, 1, e, [512, 256, 128, 1]], [-1, 1, "ADown", [512]],
+                         [-1, 1, e, [512, 512, 256, 1]], [-1, 1, "ADown", [512]], [-1, 1, e, [512, 512, 256, 1]],
+                         [-1, 1, "SPPELAN", [512, 256]]],
+            "head": [[-1, 1, "nn.Upsample", [None, 2, "nearest"]], [[-1, 6], 1, "Concat", [1]], [-1, 1, e, [512, 512, 256, 1]],
+                     [-1, 1, "nn.Upsample", [None, 2, "nearest"]], [[-1, 4], 1, "Concat", [1]], [-1, 1, e, [256, 256, 128, 1]],
+                     [-1, 1, "ADown", [256]], [[-1, 12], 1, "Concat", [1]], [-1, 1, e, [512, 512, 256, 1]],
+                     [-1, 1, "ADown", [512]], [[-1, 9], 1, "Concat", [1]], [-1, 1, e, [512, 512, 256, 1]],
+                     [[15, 18, 21], 1, "Segment", ["nc", 32, 256]]]}
+
+
+def _finish_model(layers: List[nn.Module], froms, yaml: Dict, nc: int, names: Dict[int, str],
+                  state_dict: Dict[str, torch.Tensor], train_args: Optional[Dict]) -> nn.Module:
+    """Tag the layers the way upstream's parse_model does (``i / f / type / np``), wrap them as ``SegmentationModel`` and
+    load ``state_dict`` (upstream key names, strict)."""
+    for i, (m, f) in enumerate(zip(layers, froms)):
+        m.i, m.f = i, f
+        name = type(m).__name__
+        m.type = "torch.nn.modules.upsampling.Upsample" if name == "Upsample" else f"{_UP[name]}.{name}"
+        m.np = sum(p.numel() for p in m.parameters())
+    model = _cls("SegmentationModel")()
+    model.yaml = yaml
+    model.model = nn.Sequential(*layers)
+    model.save = [4, 6, 9, 12, 15, 18, 21]           # layers whose output a later layer reads (sorted)
+    model.names = {int(k): str(v) for k, v in names.items()}
+    model.inplace = True
+    model.stride = torch.tensor([8.0, 16.0, 32.0])
+    model.nc = nc
+    model.args = dict(train_args or {})
+    model.task = "segment"
+    want = OrderedDict((k, v) for k, v in model.state_dict().items())
+    missing = [k for k in want if k not in state_dict]
+    if missing:
+        raise KeyError(f"state dict misses {len(missing)} upstream keys, e.g. {missing[:3]}")
+    model.load_state_dict({k: state_dict[k] for k in want}, strict=True)
+    return model.eval()
+
+
+def build_upstream_module_v9c(nc: int, names: Dict[int, str], state_dict: Dict[str, torch.Tensor],
+                              train_args: Optional[Dict] = None) -> nn.Module:
+    """The yolov9c-seg ``SegmentationModel`` stand-in graph: the same 23 entries, same froms and same saved layers as the
+    yolov8-seg graph, GELAN blocks in place of C2f / SPPF and ADown in place of the stride-2 convs."""
+    layers: List[nn.Module] = [
+        _conv(3, 64, 3, 2), _conv(64, 128, 3, 2), _elan(128, 256, 128, 64), _adown(256, 256), _elan(256, 512, 256, 128),
+        _adown(512, 512), _elan(512, 512, 512, 256), _adown(512, 512), _elan(512, 512, 512, 256), _sppelan(512, 512, 256),
+        nn.Upsample(None, 2, "nearest"), _concat(), _elan(1024, 512, 512, 256),
+        nn.Upsample(None, 2, "nearest"), _concat(), _elan(1024, 256, 256, 128),
+        _adown(256, 256), _concat(), _elan(768, 512, 512, 256),
+        _adown(512, 512), _concat(), _elan(1024, 512, 512, 256),
+        _segment(nc, NM, 256, (256, 512, 512)),
+    ]
+    froms = [-1] * 10 + [-1, [-1, 6], -1, -1, [-1, 4], -1, -1, [-1, 12], -1, -1, [-1, 9], -1, [15, 18, 21]]
+    return _finish_model(layers, froms, _yaml_v9c(nc), nc, names, state_dict, train_args)
+
+
 def build_upstream_module(scale: str, nc: int, names: Dict[int, str], state_dict: Dict[str, torch.Tensor],
                           train_args: Optional[Dict] = None) -> nn.Module:
     """The ``SegmentationModel`` stand-in graph holding ``state_dict`` (upstream key names)."""
+    if scale == V9C:
+        return build_upstream_module_v9c(nc, names, state_dict, train_args)
     depth, width, maxc = SCALES[scale]
     ch = lambda c: _make_divisible(min(c, maxc) * width, 8)  # noqa: E731
     rep = lambda n: max(round(n * depth), 1) if n > 1 else n  # noqa: E731
@@ -164,29 +294,7 @@ def build_upstream_module(scale: str, nc: int, names: Dict[int, str], state_dict
         _segment(nc, NM, ch(256), (c256, c512, c1024)),
     ]
     froms = [-1] * 10 + [-1, [-1, 6], -1, -1, [-1, 4], -1, -1, [-1, 12], -1, -1, [-1, 9], -1, [15, 18, 21]]
-    types_ = {"Conv": "ultralytics.nn.modules.conv.Conv", "C2f": "ultralytics.nn.modules.block.C2f",
-              "SPPF": "ultralytics.nn.modules.block.SPPF", "Concat": "ultralytics.nn.modules.conv.Concat",
-              "Segment": "ultralytics.nn.modules.head.Segment", "Upsample": "torch.nn.modules.upsampling.Upsample"}
-    for i, (m, f) in enumerate(zip(layers, froms)):
-        m.i, m.f = i, f
-        m.type = types_[type(m).__name__]
-        m.np = sum(p.numel() for p in m.parameters())
-    model = _cls("SegmentationModel")()
-    model.yaml = _yaml(scale, nc)
-    model.model = nn.Sequential(*layers)
-    model.save = [4, 6, 9, 12, 15, 18, 21]           # layers whose output a later layer reads (sorted)
-    model.names = {int(k): str(v) for k, v in names.items()}
-    model.inplace = True
-    model.stride = torch.tensor([8.0, 16.0, 32.0])
-    model.nc = nc
-    model.args = dict(train_args or {})
-    model.task = "segment"
-    want = OrderedDict((k, v) for k, v in model.state_dict().items())
-    missing = [k for k in want if k not in state_dict]
-    if missing:
-        raise KeyError(f"state dict misses {len(missing)} upstream keys, e.g. {missing[:3]}")
-    model.load_state_dict({k: state_dict[k] for k in want}, strict=True)
-    return model.eval()
+    return _finish_model(layers, froms, _yaml(scale, nc), nc, names, state_dict, train_args)
 
 
 def export_upstream_checkpoint(path: str, scale: str, nc: int, names: Dict[int, str], state_dict: Dict[str, torch.Tensor],

@@ -131,6 +131,14 @@ int m355_conv2d_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, cons
                     const float* h_bias, int cout, int k, int stride, int act,
                     const void* d_res_f16_nhwc, void* d_y_f16_nhwc, int out_f32, int force_tile,
                     void* stream);
+/* A whole C2f block body with 32 hidden channels in ONE launch (csrc/c2f_c32.hip; upstream nn.modules.block.C2f with
+ * n = 1 after its cv1):  t = SiLU(conv3x3(y1; wa) + ba);  y2 = SiLU(conv3x3(t; wb) + bb) (+ y1 if shortcut);
+ * out = SiLU(conv1x1([y0, y1, y2]; wc) + bc).  d_x fp16 NHWC (B,H,W,64) = [y0, y1]; d_y fp16 NHWC (B,H,W,64);
+ * h_wa / h_wb fp32 (32,32,3,3), h_wc fp32 (64,96,1,1), biases fp32: HOST pointers (BN folded), packed + uploaded
+ * here.  H % 8 == 0 and W % 16 == 0.  [sync] */
+int m355_c2f_c32_fwd(const void* d_x_f16_nhwc, int B, int H, int W, const float* h_wa, const float* h_ba,
+                     const float* h_wb, const float* h_bb, const float* h_wc, const float* h_bc, int shortcut,
+                     void* d_y_f16_nhwc, void* stream);
 /* Data gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2, no bias) (SURVEY A13 backward): dY fp16 NHWC
  * (B,Ho,Wo,cout) -> dX fp16 NHWC (B,H,W,cin).  Runs on the same implicit-GEMM kernel: stride 1 = convolution
  * with the spatially flipped, channel-transposed weights; stride 2 = transposed-stride gather.  h_w is the

@@ -83,3 +83,52 @@ def test_export_is_loadable_by_class_reference_and_round_trips(tmp_path, scale, 
         assert torch.equal(up["state_dict"][k].float() if v.is_floating_point() else up["state_dict"][k], ref), k
     again = YOLO(path)
     assert again.scale == scale and again.nc == nc and again.names == {i: f"defect{i}" for i in range(nc)}
+
+
+def test_v9c_export_is_loadable_by_class_reference_and_round_trips(tmp_path):
+    """The checkpoint /root/reference/BscanBased/yolo8_seg_predict.py:4-5 loads is a yolov9c-seg one: the exporter writes that
+    graph too (GELAN stand-ins RepNCSPELAN4 / RepCSP / RepBottleneck / RepConv / ADown / SPPELAN at upstream's paths)."""
+    sd = synthetic_state_dict("9c", 2, seed=4)
+    m = YOLO("yolov9c-seg.yaml")
+    m.set_classes(2, {0: "defect", 1: "porosity"})
+    m.load_state_dict(sd)
+    m.train_args = {"imgsz": 320, "data": "data-seg.yaml", "epochs": 30}
+    path = str(tmp_path / "yolo9c-seg" / "segmentation320" / "weights" / "best.pt")
+    m.save(path, upstream=True)
+    assert "ultralytics.nn.tasks" not in sys.modules
+    g = _globals_of(path)
+    for cls, mod in (("SegmentationModel", "ultralytics.nn.tasks"), ("Segment", "ultralytics.nn.modules.head"),
+                     ("Conv", "ultralytics.nn.modules.conv"), ("RepConv", "ultralytics.nn.modules.conv"),
+                     ("Concat", "ultralytics.nn.modules.conv"), ("RepNCSPELAN4", "ultralytics.nn.modules.block"),
+                     ("RepCSP", "ultralytics.nn.modules.block"), ("RepBottleneck", "ultralytics.nn.modules.block"),
+                     ("ADown", "ultralytics.nn.modules.block"), ("SPPELAN", "ultralytics.nn.modules.block"),
+                     ("Proto", "ultralytics.nn.modules.block"), ("DFL", "ultralytics.nn.modules.block")):
+        assert (mod, cls) in g, (mod, cls)
+    mods = {a for a, _ in g}
+    assert ("ultralytics.nn.modules.block", "C2f") not in g and ("ultralytics.nn.modules.block", "SPPF") not in g
+    assert not any(x.startswith("defectdetection") or x.startswith("oracle") or x == "__main__" for x in mods), mods
+    with _registered():
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+    model = ck["model"]
+    assert type(model).__name__ == "SegmentationModel" and model.yaml["yaml_file"] == "yolov9c-seg.yaml"
+    got = model.state_dict()
+    assert set(got) == set(sd)
+    for k, v in sd.items():
+        assert torch.equal(got[k], v.half() if v.is_floating_point() else v), k
+    seq = model.model
+    assert [type(l).__name__ for l in seq][:10] == ["Conv", "Conv", "RepNCSPELAN4", "ADown", "RepNCSPELAN4", "ADown", "RepNCSPELAN4",
+                                                    "ADown", "RepNCSPELAN4", "SPPELAN"]
+    assert [l.i for l in seq] == list(range(23)) and model.save == [4, 6, 9, 12, 15, 18, 21]
+    rep = seq[2].cv2[0].m[0].cv1                      # RepConv: two activation-free branches, SiLU after their sum, no identity branch
+    assert type(rep).__name__ == "RepConv" and rep.bn is None and isinstance(rep.act, nn.SiLU)
+    assert isinstance(rep.conv1.act, nn.Identity) and rep.conv1.conv.kernel_size == (3, 3) and rep.conv2.conv.kernel_size == (1, 1)
+    assert seq[2].c == 64 and seq[3].c == 128 and seq[9].c == 256 and isinstance(seq[9].cv3, nn.MaxPool2d)
+    assert sum(p.numel() for p in model.parameters()) == sum(v.numel() for k, v in sd.items()
+                                                            if "running_" not in k and "num_batches" not in k)
+    up = load_upstream_checkpoint(path)
+    assert up["scale"] == "9c" and up["nc"] == 2 and up["names"] == {0: "defect", 1: "porosity"}
+    for k, v in sd.items():
+        ref = v.half().float() if v.is_floating_point() else v
+        assert torch.equal(up["state_dict"][k].float() if v.is_floating_point() else up["state_dict"][k], ref), k
+    again = YOLO(path)                                  # /root/reference/BscanBased/yolo8_seg_predict.py:5
+    assert again.scale == "9c" and again.nc == 2
