@@ -74,7 +74,7 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_SLAB = 25, TILE_M32 = 26, TILE_M32_128 = 27, TILE_M32_64x16 = 28, TILE_M32_64x8 = 29 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_SLAB = 25, TILE_M32 = 26, TILE_M32_128 = 27, TILE_M32_64x16 = 28, TILE_M32_64x8 = 29, TILE_C64R = 30, TILE_C128R = 31 };
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {
@@ -118,6 +118,12 @@ int launch_msda(const float* value, const float* loc, const float* attn, float* 
                 const float* ref = nullptr, float offset_scale = 0.f);
 int launch_dfine_decode(const float* dist, const float* project, const float* ref, float* boxes, long n, int nbins1,
                         float reg_scale, int clamp01, hipStream_t s);
+// Cin = Cout = 64, weights in registers, persistent (conv3x3_c64r.hip)
+bool conv3x3_c64r_ok(const ConvArgs& a);
+int launch_conv3x3_c64r(const ConvArgs& a, hipStream_t s);
+// Cin = Cout = 128, weights in registers, K split over the two waves of a SIMD, 8 x 8 tiles (conv3x3_c128r.hip)
+bool conv3x3_c128r_ok(const ConvArgs& a);
+int launch_conv3x3_c128r(const ConvArgs& a, hipStream_t s);
 // Cin = Cout = 32, weights-stationary persistent halo kernel (conv3x3_c32.hip)
 bool conv3x3_c32_ok(const ConvArgs& a);
 int launch_conv3x3_c32(const ConvArgs& a, hipStream_t s);

@@ -855,10 +855,27 @@ void annotate_ops(m355_engine* e) {
           m32 = op.tile == TILE_HALO && !wide && !getenv("M355_NO_M32") && conv3x3_m32_ok(probe) && (cout_v > 64 || ti.H * ti.W <= 1600);
           probe.ldx = 8;
           if (op.kind == OP_CONV && conv3x3_c32_ok(probe) && !getenv("M355_NO_C32")) op.tile = TILE_C32;
-          if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
+          {   // 64 -> 64 on maps the 8 x 16 tiles cover exactly: weights in registers (conv3x3_c64r.hip)
+            ConvArgs pr2 = probe;
+            pr2.ldx = ti.C; pr2.ldy = 8; pr2.Kpad = p.Kpad; pr2.M = e->desc.max_batch * Ho * Wo; pr2.x_bstride = (long)ti.H * ti.W * ti.C;
+            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && conv3x3_c64r_ok(pr2) && !getenv("M355_NO_C64R")) {
+              op.tile = TILE_C64R;
+              wide = m32 = false;
+            }
+            // 128 -> 128 on maps the wide kernel's 16 x 16 tiles do not fit (40 x 40): K split over wave pairs (conv3x3_c128r.hip)
+            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !wide && conv3x3_c128r_ok(pr2) && !getenv("M355_NO_C128R")) {
+              op.tile = TILE_C128R;
+              m32 = false;
+            }
+          }
+          if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && op.tile != TILE_C64R && op.tile != TILE_C128R && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
             op.tile = TILE_SLAB;
         }
-        if (op.tile == TILE_C32)
+        if (op.tile == TILE_C128R)
+          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c128r<128ch,8x8px>");
+        else if (op.tile == TILE_C64R)
+          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c64r<64ch,8x16px>");
+        else if (op.tile == TILE_C32)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c32<32ch,16x16px>");
         else if (op.tile == TILE_SLAB)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_slab<64ch,rows>");
@@ -1299,6 +1316,8 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         }
         rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
              : (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
+             : (op.tile == TILE_C64R) ? launch_conv3x3_c64r(a, s)
+             : (op.tile == TILE_C128R) ? launch_conv3x3_c128r(a, s)
              : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
                                     : (op.tile == TILE_SLAB ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, op.tile, s)));
         break;
@@ -1531,7 +1550,9 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   }
   int rc = 0;
   for (int rep = 0; rep < (a.dbg ? 5 : 1); ++rep)
-    rc = (force_tile >= 0 && (force_tile & 0xff) == TILE_C32)
+    rc = (force_tile >= 0 && (force_tile & 0xff) == TILE_C64R) ? launch_conv3x3_c64r(a, s)
+         : (force_tile >= 0 && (force_tile & 0xff) == TILE_C128R) ? launch_conv3x3_c128r(a, s)
+         : (force_tile >= 0 && (force_tile & 0xff) == TILE_C32)
              ? launch_conv3x3_c32(a, s)
              : ((force_tile >= 0 && (force_tile & 0xff) >= TILE_HALO) ? launch_conv3x3_halo(a, (force_tile & 0xff) - TILE_HALO, s)
                                                                        : launch_conv_igemm(a, force_tile, s));

@@ -228,9 +228,6 @@ class YOLO:
     # ------------------------------------------------------------------ training
     def train(self, data: Optional[str] = None, epochs: int = 100, imgsz: int = 640, batch: int = 16,
               project: Optional[str] = None, name: Optional[str] = None, device=0, **kwargs):
-        if self.scale == V9C:
-            raise NotImplementedError("yolov9c-seg: the inference graph is built (predict / val); its training graph (RepConvN "
-                                      "branches, ADown backward) is not -- train a yolov8{n,s,m,l,x}-seg model (SURVEY.md 8(f) N4)")
         from .train import train as _train  # lazy: training pulls in the loss / dataset modules
         return _train(self, data=data, epochs=epochs, imgsz=imgsz, batch=batch, project=project, name=name,
                       device=device, **kwargs)

@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from ._capi import ConvLaunchArgs, WgradLaunchArgs, check, lib
-from .spec import BN_EPS, NM, REG_MAX, SCALES, ConvSpec, _make_divisible, conv_specs
+from .spec import BN_EPS, NM, REG_MAX, SCALES, V9C, ConvSpec, _make_divisible, conv_branches, conv_specs
 
 BN_MOMENTUM = 0.03
 
@@ -50,7 +50,16 @@ class TrainEngine:
             raise RuntimeError("TrainEngine needs a gfx950 GPU; there is no CPU fallback")
         self.dev = torch.device("cuda", device)
         self.scale, self.nc, self.imgsz, self.B = scale, nc, tuple(imgsz), batch
-        self.specs: Dict[str, ConvSpec] = {s.name: s for s in conv_specs(scale, nc)}
+        # RepConvN (yolov9c-seg) trains in its un-merged form: the 3x3 and the 1x1 branch are two Conv + BN of their own
+        # (state-dict prefixes <name>.conv1 / <name>.conv2), summed before the SiLU
+        self.specs: Dict[str, ConvSpec] = {}
+        for s in conv_specs(scale, nc):
+            if s.rep:
+                for pre, k in conv_branches(s):
+                    self.specs[pre] = ConvSpec(pre, s.cin, s.cout, k, 1, True)
+            else:
+                self.specs[s.name] = s
+        self.galias: Dict[int, int] = {}     # tensor -> tensor whose gradient buffer it shares (the two RepConvN branches)
         self.tensors: List[torch.Tensor] = []
         self.gtensors: List[Optional[torch.Tensor]] = []
         self.ops: List[dict] = []
@@ -87,10 +96,11 @@ class TrainEngine:
         self.gtensors.append(None)
         return len(self.tensors) - 1
 
-    def _conv(self, name, src: Slice, dst: Slice, res: Optional[Slice] = None):
+    def _conv(self, name, src: Slice, dst: Slice, res: Optional[Slice] = None, act: int = 1):
         s = self.specs[name]
         assert s.cin == src.c or (s.cin == 3 and src.c == 8), (name, s.cin, src.c)
-        self.ops.append(dict(kind="conv", name=name, src=src, dst=dst, res=res, k=s.k, s=s.stride))
+        assert s.cout == dst.c, (name, s.cout, dst.c)
+        self.ops.append(dict(kind="conv", name=name, src=src, dst=dst, res=res, k=s.k, s=s.stride, act=act))
 
     def _c2f(self, name, src: Slice, dst: Slice, n: int, shortcut: bool):
         H, W = self.tensors[src.t].shape[1:3]
@@ -104,7 +114,91 @@ class TrainEngine:
             self._conv(f"{name}.m.{j}.cv2", Slice(tmp, 0, c), Slice(cat, (2 + j) * c, c), s_in if shortcut else None)
         self._conv(f"{name}.cv2", Slice(cat, 0, (2 + n) * c), dst)
 
+    # ---- yolov9c-seg blocks (oracle/yolov9c_seg_oracle.py; /root/reference/BscanBased/yolo_seg_train.py:7 builds this graph)
+    def _repconv(self, name, src: Slice, dst: Slice):
+        """RepConvN: dst = SiLU(BN(conv3x3(src)) + BN(conv1x1(src))).  The two branches run as activation-free Conv + BN ops
+        into temporaries that share ONE gradient buffer (both receive d SiLU(a + b) / d(a + b) x the incoming gradient)."""
+        H, W = self.tensors[src.t].shape[1:3]
+        ta, tb = self._tensor(H, W, dst.c), self._tensor(H, W, dst.c)
+        self.galias[tb] = ta
+        self._conv(f"{name}.conv1", src, Slice(ta, 0, dst.c), act=0)
+        self._conv(f"{name}.conv2", src, Slice(tb, 0, dst.c), act=0)
+        self.ops.append(dict(kind="addsilu", name=name, a=Slice(ta, 0, dst.c), b=Slice(tb, 0, dst.c), dst=dst))
+
+    def _repcsp(self, name, src: Slice, dst: Slice):
+        H, W = self.tensors[src.t].shape[1:3]
+        c_ = dst.c // 2
+        icat, u, r = self._tensor(H, W, 2 * c_), self._tensor(H, W, c_), self._tensor(H, W, c_)
+        self._conv(f"{name}.cv1", src, Slice(u, 0, c_))
+        self._repconv(f"{name}.m.0.cv1", Slice(u, 0, c_), Slice(r, 0, c_))                       # RepBottleneck: x + cv2(cv1(x))
+        self._conv(f"{name}.m.0.cv2", Slice(r, 0, c_), Slice(icat, 0, c_), Slice(u, 0, c_))
+        self._conv(f"{name}.cv2", src, Slice(icat, c_, c_))
+        self._conv(f"{name}.cv3", Slice(icat, 0, 2 * c_), dst)
+
+    def _elan(self, name, src: Slice, dst: Slice, c3: int, c4: int):
+        """RepNCSPELAN4: y = chunk2(cv1(x)); y += [cv2(y[-1])]; y += [cv3(y[-1])]; cv4(cat(y)); zero-copy concat."""
+        H, W = self.tensors[src.t].shape[1:3]
+        cat = self._tensor(H, W, c3 + 2 * c4)
+        ta, tb = self._tensor(H, W, c4), self._tensor(H, W, c4)
+        self._conv(f"{name}.cv1", src, Slice(cat, 0, c3))
+        self._repcsp(f"{name}.cv2.0", Slice(cat, c3 // 2, c3 // 2), Slice(ta, 0, c4))
+        self._conv(f"{name}.cv2.1", Slice(ta, 0, c4), Slice(cat, c3, c4))
+        self._repcsp(f"{name}.cv3.0", Slice(cat, c3, c4), Slice(tb, 0, c4))
+        self._conv(f"{name}.cv3.1", Slice(tb, 0, c4), Slice(cat, c3 + c4, c4))
+        self._conv(f"{name}.cv4", Slice(cat, 0, c3 + 2 * c4), dst)
+
+    def _adown(self, name, src: Slice, dst: Slice):
+        """ADown: x = avg_pool2d(x, 2, 1, 0); x1, x2 = chunk2(x); cat(Conv3x3/s2(x1), Conv1x1(max_pool2d(x2, 3, 2, 1)))."""
+        H, W = self.tensors[src.t].shape[1:3]
+        ch = src.c // 2
+        p1, p2 = self._tensor(H - 1, W - 1, ch), self._tensor(H // 2, W // 2, ch)
+        self.ops.append(dict(kind="adown", src=src, p1=Slice(p1, 0, ch), p2=Slice(p2, 0, ch)))
+        self._conv(f"{name}.cv1", Slice(p1, 0, ch), Slice(dst.t, dst.off, dst.c // 2))
+        self._conv(f"{name}.cv2", Slice(p2, 0, ch), Slice(dst.t, dst.off + dst.c // 2, dst.c // 2))
+
+    def _build_v9c(self):
+        H, W = self.imgsz
+        T = self._tensor
+        self.x8 = T(H, W, 8)
+        cat11 = T(H // 16, W // 16, 1024)          # [up(x9), x6]
+        cat14 = T(H // 8, W // 8, 1024)            # [up(x12), x4]
+        cat17 = T(H // 16, W // 16, 768)           # [adown(x15), x12]
+        cat20 = T(H // 32, W // 32, 1024)          # [adown(x18), x9]
+        x4, x6 = Slice(cat14, 512, 512), Slice(cat11, 512, 512)
+        x9, x12 = Slice(cat20, 512, 512), Slice(cat17, 256, 512)
+        t0, t1, t2 = T(H // 2, W // 2, 64), T(H // 4, W // 4, 128), T(H // 4, W // 4, 256)
+        self._conv("model.0", Slice(self.x8, 0, 8), Slice(t0, 0, 64))
+        self._conv("model.1", Slice(t0, 0, 64), Slice(t1, 0, 128))
+        self._elan("model.2", Slice(t1, 0, 128), Slice(t2, 0, 256), 128, 64)
+        t3 = T(H // 8, W // 8, 256)
+        self._adown("model.3", Slice(t2, 0, 256), Slice(t3, 0, 256))
+        self._elan("model.4", Slice(t3, 0, 256), x4, 256, 128)
+        t5 = T(H // 16, W // 16, 512)
+        self._adown("model.5", x4, Slice(t5, 0, 512))
+        self._elan("model.6", Slice(t5, 0, 512), x6, 512, 256)
+        t7, t8 = T(H // 32, W // 32, 512), T(H // 32, W // 32, 512)
+        self._adown("model.7", x6, Slice(t7, 0, 512))
+        self._elan("model.8", Slice(t7, 0, 512), Slice(t8, 0, 512), 512, 256)
+        sp = T(H // 32, W // 32, 1024)             # SPPELAN = SPPF's shape: cv1, three serial 5x5 max-pools, cv5 over the concat
+        self._conv("model.9.cv1", Slice(t8, 0, 512), Slice(sp, 0, 256))
+        self.ops.append(dict(kind="pool", src=Slice(sp, 0, 256), dst=Slice(sp, 256, 768)))
+        self._conv("model.9.cv5", Slice(sp, 0, 1024), x9)
+        self.ops.append(dict(kind="up", src=x9, dst=Slice(cat11, 0, 512)))
+        self._elan("model.12", Slice(cat11, 0, 1024), x12, 512, 256)
+        self.ops.append(dict(kind="up", src=x12, dst=Slice(cat14, 0, 512)))
+        t15 = T(H // 8, W // 8, 256)
+        self._elan("model.15", Slice(cat14, 0, 1024), Slice(t15, 0, 256), 256, 128)
+        self._adown("model.16", Slice(t15, 0, 256), Slice(cat17, 0, 256))
+        t18 = T(H // 16, W // 16, 512)
+        self._elan("model.18", Slice(cat17, 0, 768), Slice(t18, 0, 512), 512, 256)
+        self._adown("model.19", Slice(t18, 0, 512), Slice(cat20, 0, 512))
+        t21 = T(H // 32, W // 32, 512)
+        self._elan("model.21", Slice(cat20, 0, 1024), Slice(t21, 0, 512), 512, 256)
+        self._build_head((t15, t18, t21), (256, 512, 512), 256)
+
     def _build(self):
+        if self.scale == V9C:
+            return self._build_v9c()
         depth, width, maxc = SCALES[self.scale]
         ch = lambda c: _make_divisible(min(c, maxc) * width, 8)  # noqa: E731
         rep = lambda n: max(round(n * depth), 1) if n > 1 else n  # noqa: E731
@@ -150,10 +244,14 @@ class TrainEngine:
         self._conv("model.19", Slice(t18, 0, c512), Slice(cat20, 0, c512))
         t21 = T(H // 32, W // 32, c1024)
         self._c2f("model.21", Slice(cat20, 0, c512 + c1024), Slice(t21, 0, c1024), rep(3), False)
-        # head
-        feats, fch = (t15, t18, t21), (c256, c512, c1024)
+        self._build_head((t15, t18, t21), (c256, c512, c1024), ch(256))
+
+    def _build_head(self, feats, fch, npr):
+        """model.22 = Segment on the three feature tensors (shared by the yolov8-seg and the yolov9c-seg graphs)."""
+        H, W = self.imgsz
+        T = self._tensor
+        t15, c256 = feats[0], fch[0]
         hc2, hc3, hc4 = max(16, fch[0] // 4, REG_MAX * 4), max(fch[0], min(self.nc, 100)), max(fch[0] // 4, NM)
-        npr = ch(256)
         hw = [(H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
         self.level_n = [h * w for h, w in hw]
         self.A = sum(self.level_n)
@@ -415,7 +513,7 @@ class TrainEngine:
             rv = self.params[f"{name}.bn.running_var"].data_ptr() if update_running_stats else 0
             check(lib.m355_bn_train_fwd_launch(sv["z"].data_ptr(), B * ho * wo, cout, cout,
                                                self.params[f"{name}.bn.weight"].data_ptr(),
-                                               self.params[f"{name}.bn.bias"].data_ptr(), BN_EPS, 1, yp, ldy, rp, ldr,
+                                               self.params[f"{name}.bn.bias"].data_ptr(), BN_EPS, op.get("act", 1), yp, ldy, rp, ldr,
                                                sv["mean"].data_ptr(), sv["invstd"].data_ptr(), sv["ws"].data_ptr(),
                                                rm, rv, BN_MOMENTUM, st))
         elif kind == "plain":
@@ -450,6 +548,26 @@ class TrainEngine:
             xp, xbs, ldx = self._slice_ptr(self.tensors, src)
             yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
             check(lib.m355_upsample2x_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
+        elif kind == "addsilu":
+            # RepConvN's tail: SiLU(a + b) of the two activation-free branches.  Byte-moving elementwise glue (torch): the
+            # FLOP-carrying parts -- both convolutions, both batch-norms -- ran in the HIP kernels just before.
+            a, b, dst = self._tview(op["a"]), self._tview(op["b"]), self._tview(op["dst"])
+            v = op.get("_v")
+            if v is None:
+                v = op["_v"] = torch.empty(a.shape, dtype=torch.float16, device=self.dev)
+            torch.add(a, b, out=v)                                           # kept for the backward pass (fp16 like every activation)
+            dst.copy_(F.silu(v.float()))
+        elif kind == "adown":
+            # ADown's pooling front (2x2 average at stride 1, channel split, 3x3 / s2 max-pool of the second half): pooling
+            # glue on torch, its two convolutions follow as ordinary conv ops
+            x = self._tview(op["src"]).permute(0, 3, 1, 2)
+            c = op["src"].c // 2
+            a = F.avg_pool2d(x.float(), 2, 1, 0)
+            self._tview(op["p1"]).copy_(a[:, :c].permute(0, 2, 3, 1))
+            self._tview(op["p2"]).copy_(F.max_pool2d(a[:, c:], 3, 2, 1).permute(0, 2, 3, 1))
+
+    def _tview(self, sl: Slice) -> torch.Tensor:
+        return self.tensors[sl.t][..., sl.off:sl.off + sl.c]
 
     # ------------------------------------------------------------------ forward
     def forward(self, images_u8_nhwc: torch.Tensor, update_running_stats: bool = True):
@@ -534,8 +652,10 @@ class TrainEngine:
         st = self._stream()
         d_raw = d_raw.float().contiguous()                                  # no-ops for the loss's own gradient buffer
         for i, t in enumerate(self.tensors):
-            if self.gtensors[i] is None:
+            if self.gtensors[i] is None and i not in self.galias:
                 self.gtensors[i] = torch.zeros_like(t)
+        for i, j in self.galias.items():                                    # RepConvN branches: one gradient buffer for both
+            self.gtensors[i] = self.gtensors[j]
         written: Dict[int, list] = {}                                     # tensor -> channel intervals written in this backward
         level_bias: Dict[int, torch.Tensor] = {}                          # level offset -> per-channel sums of d_raw over the level
         self.gtensors[self.protos_t].copy_(d_protos.to(torch.float16))
@@ -573,7 +693,7 @@ class TrainEngine:
                 check(lib.m355_bn_train_bwd_launch(sv["z"].data_ptr(), dyp, B * ho * wo, cout, lddy, cout,
                                                    sv["mean"].data_ptr(), sv["invstd"].data_ptr(),
                                                    self.params[f"{name}.bn.weight"].data_ptr(),
-                                                   self.params[f"{name}.bn.bias"].data_ptr(), 1, sv["dz"].data_ptr(), cout,
+                                                   self.params[f"{name}.bn.bias"].data_ptr(), op.get("act", 1), sv["dz"].data_ptr(), cout,
                                                    gb.data_ptr(), sv["ws"].data_ptr(), st))
                 ready += [f"{name}.bn.bias", f"{name}.bn.weight", f"{name}.conv.weight"]
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
@@ -673,6 +793,27 @@ class TrainEngine:
                         self._gview(src).copy_(ga.permute(0, 2, 3, 1))
                     else:
                         self._gview(src).add_(ga.permute(0, 2, 3, 1).half())
+            elif kind == "addsilu":                                        # y = SiLU(v), v = a + b: dv = dy * SiLU'(v) for BOTH branches
+                a_, b_, dst = op["a"], op["b"], op["dst"]
+                self._ensure(written, dst)
+                v = op["_v"].float()
+                sig = torch.sigmoid(v)
+                self.gtensors[a_.t].copy_(self._gview(dst).float() * (sig * (1.0 + v * (1.0 - sig))))
+                written[a_.t] = [(0, a_.c)]
+                written[b_.t] = [(0, b_.c)]                                 # (the same buffer: galias)
+            elif kind == "adown":                                          # pooling backward through autograd on fp32 NCHW copies
+                src, p1, p2 = op["src"], op["p1"], op["p2"]
+                self._ensure(written, p1)
+                self._ensure(written, p2)
+                c = src.c // 2
+                x = self._tview(src).permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)
+                a = F.avg_pool2d(x, 2, 1, 0)
+                y1, y2 = a[:, :c], F.max_pool2d(a[:, c:], 3, 2, 1)
+                (gx,) = torch.autograd.grad((y1, y2), x, (self._gview(p1).permute(0, 3, 1, 2).float(), self._gview(p2).permute(0, 3, 1, 2).float()))
+                if self._claim(written, src):
+                    self._gview(src).copy_(gx.permute(0, 2, 3, 1))
+                else:
+                    self._gview(src).add_(gx.permute(0, 2, 3, 1).half())
             elif kind == "up":
                 src, dst = op["src"], op["dst"]
                 self._ensure(written, dst)

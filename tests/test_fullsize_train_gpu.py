@@ -56,10 +56,11 @@ def test_one_full_size_training_step(scale, cuda_device):
     assert np.isfinite(loss) and loss > 0 and bad == 0 and sumsq > 0
     assert torch.isfinite(raw).all() and torch.isfinite(protos.float()).all()
     # every parameter tensor received a gradient (a layer whose kernel wrote nothing would stay at the zero fill).  The box
-    # branch of a head level (model.22.cv2.<level>.*) is the exception: its gradient comes through foreground anchors only
-    # and the assignment may put none on a level -- at least one level has them.
+    # and coefficient branches of a head level (model.22.cv2 / cv4.<level>.*) are the exception: their gradients come through
+    # foreground anchors only and the assignment may put none on a level -- at least one level has them.
     dead = [k for k, (o, sh) in eng.layout.items() if o < eng.n_train and not bool(grads[o:o + int(np.prod(sh))].any())]
-    assert all(k.startswith("model.22.cv2.") for k in dead), [k for k in dead if not k.startswith("model.22.cv2.")][:5]
+    fg_only = ("model.22.cv2.", "model.22.cv4.")
+    assert all(k.startswith(fg_only) for k in dead), [k for k in dead if not k.startswith(fg_only)][:5]
     assert len({k.split(".")[3] for k in dead}) < 3, dead[:5]
     for o in outs[1:]:
         assert torch.equal(o[0], raw) and torch.equal(o[1], protos)

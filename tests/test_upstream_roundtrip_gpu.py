@@ -14,25 +14,25 @@ pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-@pytest.mark.parametrize("arch,scale,cls_bias", [("yolov9c-seg", "9c", -2.5), ("yolov8n-seg", "n", -2.0)])
-def test_upstream_layout_file_predicts_like_its_source(tmp_path, cuda_device, arch, scale, cls_bias):
+@pytest.mark.parametrize("arch,scale,cls_bias,seed", [("yolov9c-seg", "9c", -2.5, 2), ("yolov8n-seg", "n", -2.0, 0)])
+def test_upstream_layout_file_predicts_like_its_source(tmp_path, cuda_device, arch, scale, cls_bias, seed):
     from ultralytics import YOLO                      # the shim
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
-    sd = synthetic_state_dict(scale, 1, seed=2, cls_bias=cls_bias)
+    sd = synthetic_state_dict(scale, 1, seed=seed, cls_bias=cls_bias)
     sd = {k: (v.half().float() if v.is_floating_point() else v) for k, v in sd.items()}     # what a .half() checkpoint can hold
     src = YOLO(f"{arch}.yaml")
     src.set_classes(1, {0: "defect"})
     src.load_state_dict(sd)
-    src.train_args = {"imgsz": 320}
+    src.train_args = {"imgsz": 640}
     path = src.save(str(tmp_path / arch / "segmentation320" / "weights" / "best.pt"), upstream=True)
     with pytest.raises(Exception):                    # it IS upstream's layout: plain torch.load needs upstream's classes
         torch.load(path, map_location="cpu", weights_only=False)
     model = YOLO(path)                                # yolo8_seg_predict.py:5
-    assert model.scale == scale and model.nc == 1 and model.names == {0: "defect"} and model.train_args["imgsz"] == 320
+    assert model.scale == scale and model.nc == 1 and model.names == {0: "defect"} and model.train_args["imgsz"] == 640
     for k, v in sd.items():
         assert torch.equal(model.state_dict[k], v), k
     png = os.path.join(GOLDEN, "bscans", "787-225_01_Ch-0_51.png")
-    a = src.predict(png, verbose=False, conf=0.25)[0]             # imgsz from the checkpoint's train args (D7): 320
+    a = src.predict(png, verbose=False, conf=0.25)[0]             # imgsz from the checkpoint's train args (D7)
     b = model.predict(png, save=True, project=str(tmp_path / "runs"), name="predict", verbose=False, conf=0.25)[0]   # :8
     assert len(b.boxes) > 0, "the synthetic weights must detect something on the fixture"
     assert np.array_equal(a.boxes.data.numpy(), b.boxes.data.numpy())

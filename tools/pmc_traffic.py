@@ -4,6 +4,7 @@ coalesced streaming reads -> doubled; WRITE_SIZE is exact for 16-byte-per-lane s
 import csv, json, re, sys, collections
 
 LABELS = {
+    "c2f_c32_kernel": "c2f_c32<8x16px>",
     "conv3x3_halo_kernel<4, 4, 2, 2>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 4>": "conv3x3_halo<64ch>",
     "conv3x3_halo_kernel<4, 4, 2, 4>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 8>": "conv3x3_halo<64ch>",
     "conv_igemm_kernel<4, 4, 2, 2, 3>": "conv_igemm<128x128,k3>", "conv_igemm_kernel<4, 4, 2, 2, 1>": "conv_igemm<128x128,k1>",

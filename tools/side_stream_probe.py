@@ -6,6 +6,9 @@
   C  TWO independent processes on the same GPU, side streams on, started together, NO process group
   D  two independent processes, side streams off
   E  one process, TWO THREADS each with its own TrainEngine and side streams on (same HIP context / same queues' owner)
+  F  two processes AS TWO RANKS of a gloo process group (the round-2 rehearsal itself): bucketed gradient all-reduce under
+     backward, side streams forced on (M355_SIDE_STREAMS=1)
+  G  the same two ranks, side streams off (what a multi-rank job runs today)
 
 If C collapses like the round-2 rehearsal did and E does not, the cause is the time-slicing of hardware queues between
 PROCESSES (each cross-stream event wait ends up waiting for the other process's queue quantum), not torch.distributed and
@@ -23,9 +26,12 @@ sys.path.insert(0, ROOT)
 SCALE, B, S = "n", 16, 320
 
 
-def run_steps(steps, tag, out, gate=None):
+def run_steps(steps, tag, out, gate=None, ddp=False):
     import numpy as np
     import torch
+    if ddp:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
     from defectdetection_viaobjectdetection_amd.loss import SegCriterion
     from defectdetection_viaobjectdetection_amd.spec import init_state_dict
     from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
@@ -43,12 +49,20 @@ def run_steps(steps, tag, out, gate=None):
         masks[:, 20:40, 20:40] = 1
         batch = {"batch_idx": torch.arange(B).repeat_interleave(2).float(), "cls": torch.zeros(n), "bboxes": boxes, "masks": masks}
         crit = SegCriterion(1, (S, S))
+        reducer = None
+        if ddp:
+            from defectdetection_viaobjectdetection_amd.sharding import GradBucketReducer
+            reducer = GradBucketReducer(eng.flat_grads, eng.grad_spans(), bucket_bytes=1 << 20)
 
         def step():
             prep = crit.prepare(batch, B, dev)
             raw, protos = eng.forward(imgs)
             items, d_raw, d_protos = crit(raw, protos, prep, 128.0)
-            eng.backward(d_raw, d_protos)
+            if reducer is not None:
+                reducer.reset()
+            eng.backward(d_raw, d_protos, on_ready=reducer.mark_ready if reducer is not None else None)
+            if reducer is not None:
+                reducer.finish()
             return float(items.sum())
         for _ in range(2):
             step()
@@ -62,7 +76,7 @@ def run_steps(steps, tag, out, gate=None):
         out[tag] = (time.perf_counter() - t0) / steps * 1e3
 
 
-def child(steps, barrier_file):
+def child(steps, barrier_file, ddp=False):
     def gate():
         if not barrier_file:
             return
@@ -72,19 +86,26 @@ def child(steps, barrier_file):
         while len([f for f in os.listdir(d) if f.startswith(base + ".")]) < 2 and time.time() < t_end:
             time.sleep(0.005)
     out = {}
-    run_steps(steps, "ms", out, gate)
+    run_steps(steps, "ms", out, None if ddp else gate, ddp)
     print(f"CHILD_MS {out['ms']:.3f}", flush=True)
 
 
-def spawn(n_proc, side, steps, tag):
+def spawn(n_proc, side, steps, tag, ddp=False):
     env = dict(os.environ)
-    for k in ("M355_NO_WGRAD_STREAM", "M355_NO_HEAD_STREAM"):
+    for k in ("M355_NO_WGRAD_STREAM", "M355_NO_HEAD_STREAM", "M355_SIDE_STREAMS"):
         env.pop(k, None)
-        if not side:
+        if not side and k != "M355_SIDE_STREAMS":
             env[k] = "1"
+    if ddp and side:
+        env["M355_SIDE_STREAMS"] = "1"
     bar = f"/tmp/ssp_{tag}_{os.getpid()}" if n_proc > 1 else ""
-    ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "child", str(steps), bar], env=env, stdout=subprocess.PIPE,
-                           stderr=subprocess.STDOUT, text=True) for _ in range(n_proc)]
+    ps = []
+    for r in range(n_proc):
+        e = dict(env)
+        if ddp:
+            e.update(RANK=str(r), WORLD_SIZE=str(n_proc), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29611 + (ord(tag) % 7)))
+        ps.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "child", str(steps), bar] + (["ddp"] if ddp else []), env=e,
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     res = []
     for p in ps:
         o, _ = p.communicate(timeout=900)
@@ -113,6 +134,8 @@ def main():
     for t in ts:
         t.join()
     rows.append(("E two threads in one process, side streams on", [out.get("t0", float("nan")), out.get("t1", float("nan"))]))
+    rows.append(("F two gloo ranks (DP, 1 MiB buckets), side streams on", spawn(2, True, 6, "F", ddp=True)))
+    rows.append(("G two gloo ranks (DP, 1 MiB buckets), side streams off", spawn(2, False, 6, "G", ddp=True)))
     print(f"YOLOv8{SCALE}-seg training step (forward + loss + backward), batch {B} @{S}: ms per step, per worker")
     for name, r in rows:
         print(f"  {name:48s} " + "  ".join(f"{v:9.2f}" for v in r))
@@ -120,6 +143,6 @@ def main():
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
-        child(int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "")
+        child(int(sys.argv[2]), sys.argv[3] if len(sys.argv) > 3 else "", ddp=len(sys.argv) > 4 and sys.argv[4] == "ddp")
     else:
         main()
