@@ -186,7 +186,10 @@ __global__ __launch_bounds__(512, 2) void c2f_c32_kernel(const C2fC32Args a, int
       constexpr int NB = decltype(nbc)::value;
       constexpr bool LOADER = NB == 1;
       half8 wa[18];
-      {
+      if (a.waf) {   // fragment-ordered copy: one coalesced 1 KiB load per fragment
+#pragma unroll
+        for (int s = 0; s < 18; ++s) wa[s] = *(const half8*)(a.waf + 512 * s + lane * 8);
+      } else {
         const half_t* wp = a.wa + (long)row_plain(n) * a.kpad_a + 8 * h;
 #pragma unroll
         for (int s = 0; s < 18; ++s) wa[s] = *(const half8*)(wp + 16 * s);
@@ -341,7 +344,10 @@ __global__ __launch_bounds__(512, 2) void c2f_c32_kernel(const C2fC32Args a, int
     // =====================================================================================================
     const int q = wave - 4;
     half8 wb[18];
-    {
+    if (a.wbf) {
+#pragma unroll
+      for (int s = 0; s < 18; ++s) wb[s] = *(const half8*)(a.wbf + 512 * s + lane * 8);
+    } else {
       const half_t* wp = a.wb + (long)row_operand(n) * a.kpad_b + 8 * h;
 #pragma unroll
       for (int s = 0; s < 18; ++s) wb[s] = *(const half8*)(wp + 16 * s);

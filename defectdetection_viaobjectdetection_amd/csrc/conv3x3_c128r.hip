@@ -78,7 +78,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128r_kernel(const ConvArgs a,
   // (taps 0-7 in 128 VGPRs; the four fragments of tap 8 live in this wave's 4 KB of LDS and are read once per tile -- the
   // register budget of two waves per SIMD is 256 and 144 + 32 accumulators + 32 activation fragments + addressing spilled)
   half8 wv[32];
-  {
+  if (a.wf) {      // fragment-ordered copy [m][kh][tap][slice]: one coalesced 1 KiB load per fragment
+    const half_t* wp = a.wf + (long)(m * 2 + kh_) * 36 * 512 + lane * 8;
+#pragma unroll
+    for (int f = 0; f < 32; ++f) wv[f] = *(const half8*)(wp + 512 * f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) *(half8*)(smem + W8_OFF + wave * 4096 + s * 1024 + lane * 16) = *(const half8*)(wp + 512 * (32 + s));
+  } else {
     const half_t* wp = a.w + (long)(32 * m + row_plain(n)) * a.Kpad + 64 * kh_ + 8 * h;
 #pragma unroll
     for (int tap = 0; tap < 8; ++tap)

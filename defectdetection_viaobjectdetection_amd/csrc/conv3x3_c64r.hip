@@ -74,7 +74,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
 
   // ---- this wave's weights: 36 K slices of its 32-channel block, in registers for the block's whole life
   half8 wv[36];
-  {
+  if (a.wf) {      // fragment-ordered copy: one coalesced 1 KiB load per fragment
+    const half_t* wp = a.wf + (long)m * 36 * 512 + lane * 8;
+#pragma unroll
+    for (int s = 0; s < 36; ++s) wv[s] = *(const half8*)(wp + 512 * s);
+  } else {
     const half_t* wp = a.w + (long)(32 * m + row_plain(n)) * a.Kpad + 8 * h;
 #pragma unroll
     for (int s = 0; s < 36; ++s) wv[s] = *(const half8*)(wp + 16 * s);
@@ -166,10 +170,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
   __builtin_amdgcn_s_waitcnt(0x0070);
   __builtin_amdgcn_s_barrier();                            // patches 0 and 1 landed, biases visible
 
+  // diagnostic launches only (a.stamps, M355_STAMPS through m355_conv2d_fwd): cycles per section and wave
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
+  int ntile = 0;
+#define C64_STAMP(k)                                                                                      \
+  if (a.stamps) {                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    const unsigned long long tn = __builtin_amdgcn_s_memtime();                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                    \
+    tacc[k] += tn - tlast;                                                                                \
+    tlast = tn;                                                                                           \
+  }
   for (int it = 0;; ++it) {
     plan(2);
+    ++ntile;
     const char* const pb = smem + (it % NBUF) * PATCH_BYTES;
     if (have[2]) issue_patch(tbi[2], ty0[2], tx0[2], (it + 2) % NBUF);
+    C64_STAMP(0)   // tile step + DMA issue
     // ---- K loop: 9 taps x 4 slices; the fragments of tap t + 1 are read under the MFMAs of tap t
     float16v acc;
     {
@@ -193,6 +211,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[4 * tap + s], fr[tap & 1][s], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    C64_STAMP(1)   // reads + MFMAs
     // ---- epilogue: SiLU, + residual, fp16 (the rounding order of the other conv kernels), transpose through LDS, store.
     // The residual (accumulator layout, two 16-byte loads per lane) is loaded HERE, under the SiLUs: the compiler waits for
     // it with vmcnt(0) (the conditional patch issue hides the count from it), which at the top of the tile drained the
@@ -216,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
         o1[j] = m355_to_half(v1);
       }
     }
+    C64_STAMP(2)   // residual wait + SiLU + convert
     *(half8*)(stg + st_w0) = o0;
     *(half8*)(stg + st_w1) = o1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -230,17 +250,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
     }
     // the patch of tile it + 1 (issued one iteration ago, or in the prologue) has landed for this wave: everything older than
     // this iteration's own patch pieces and stores (the residual loads were consumed above)
+    C64_STAMP(3)   // staging + stores
     if (have[2]) {
       if (wave + 2 * NWAVES < NPIECES) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   // 3 pieces + 2 stores
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                // 2 pieces + 2 stores
     } else {
       asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     }
+    C64_STAMP(4)   // next patch landed
     __builtin_amdgcn_s_barrier();
+    C64_STAMP(5)   // barrier
     if (!have[1]) break;
 #pragma unroll
     for (int k = 0; k < 2; ++k) { tbi[k] = tbi[k + 1]; ty0[k] = ty0[k + 1]; tx0[k] = tx0[k + 1]; have[k] = have[k + 1]; }
   }
+  if (a.stamps && lane == 0) {
+    unsigned long long* o = a.stamps + ((long)blockIdx.x * NWAVES + wave) * 8;
+    for (int k = 0; k < 6; ++k) o[k] = tacc[k];
+    o[6] = (unsigned long long)ntile;
+  }
+#undef C64_STAMP
 }
 
 }  // namespace

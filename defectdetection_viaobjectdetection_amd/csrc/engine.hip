@@ -87,6 +87,10 @@ struct PhysConv {
   half_t* w = nullptr;
   float* bias = nullptr;
   float* stem_w = nullptr;  // stem only: [27][cout] fp32
+  // fragment-ordered copies of `w` for the weights-in-registers kernels (frag_pack below): wf = plain row order (conv3x3_c64r /
+  // conv3x3_c128r / conv1x1_wreg / c2f_c32's first conv), wf2 = operand row order (c2f_c32's second conv); nullptr = not built
+  half_t* wf = nullptr;
+  half_t* wf2 = nullptr;
 };
 
 }  // namespace
@@ -858,12 +862,21 @@ void annotate_ops(m355_engine* e) {
           {   // 64 -> 64 on maps the 8 x 16 tiles cover exactly: weights in registers (conv3x3_c64r.hip)
             ConvArgs pr2 = probe;
             pr2.ldx = ti.C; pr2.ldy = 8; pr2.Kpad = p.Kpad; pr2.M = e->desc.max_batch * Ho * Wo; pr2.x_bstride = (long)ti.H * ti.W * ti.C;
-            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && conv3x3_c64r_ok(pr2) && !getenv("M355_NO_C64R")) {
+            // OPT-IN (M355_C64R=1): measured 27.5 us per layer against 28 on the halo kernel -- no gain
+            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && conv3x3_c64r_ok(pr2) && getenv("M355_C64R")) {
               op.tile = TILE_C64R;
               wide = m32 = false;
             }
-            // 128 -> 128 on maps the wide kernel's 16 x 16 tiles do not fit (40 x 40): K split over wave pairs (conv3x3_c128r.hip)
-            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !wide && conv3x3_c128r_ok(pr2) && !getenv("M355_NO_C128R")) {
+            // 1x1 with K <= 512 and Cout a multiple of 128: weights in registers (conv1x1_wreg.hip)
+            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !p.diag && op.in2.t < 0 && op.res.t < 0 && !op.decode) {
+              ConvArgs pr3 = pr2;
+              const Tensor& to2 = e->tensors[op.out.t];
+              pr3.ldy = to2.C; pr3.y_bstride = (long)to2.H * to2.W * to2.C;
+              if (conv1x1_wreg_ok(pr3) && !getenv("M355_NO_W1")) op.tile = TILE_W1;
+            }
+            // 128 -> 128 on maps the wide kernel's 16 x 16 tiles do not fit (40 x 40): K split over wave pairs (conv3x3_c128r.hip).
+            // OPT-IN (M355_C128R=1): measured 31 us per layer against 25-27 on the 32x32x16 halo kernel
+            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !wide && conv3x3_c128r_ok(pr2) && getenv("M355_C128R")) {
               op.tile = TILE_C128R;
               m32 = false;
             }
@@ -871,7 +884,9 @@ void annotate_ops(m355_engine* e) {
           if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && op.tile != TILE_C64R && op.tile != TILE_C128R && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
             op.tile = TILE_SLAB;
         }
-        if (op.tile == TILE_C128R)
+        if (op.tile == TILE_W1)
+          snprintf(op.kernel, sizeof(op.kernel), "conv1x1_wreg<K%d,%dch>", p.cin, cout_v % 256 == 0 ? 256 : 128);
+        else if (op.tile == TILE_C128R)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c128r<128ch,8x8px>");
         else if (op.tile == TILE_C64R)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c64r<64ch,8x16px>");
@@ -993,6 +1008,46 @@ void pack_conv_rows(const float* w, int cout, int cin, int k, int Kpad, int row0
               (half_t)w[(((size_t)co * cin + ci) * k + kh) * k + kw];
 }
 
+// Fragment-ordered copy of packed rows for the weights-in-registers kernels.  Fragment f = (first row r0 of a 32-row block,
+// first K element k0 of a 16-deep slice); out[(f * 64 + lane) * 8 + j] = rows[(r0 + perm(lane & 31)) * Kpad + k0 + 8 * (lane >> 5)
+// + j]: exactly the A operand of one v_mfma_f32_32x32x16_f16, so a wave fetches a fragment with ONE coalesced 1 KiB load
+// (lane-linear 16 bytes) instead of 64 scattered 16-byte pieces of 32 different rows (measured: the scattered prologue of
+// conv3x3_c64r cost ~10 us of a 31 us launch).  perm: plain (lane-half h's accumulators = channels 16 h + r) or operand
+// (c2f_c32.hip: accumulators = the next MFMA's B fragments).
+int frag_row(int rho, bool operand) {
+  if (!operand) return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
+  const int q = rho >> 3, h = (rho >> 2) & 1, i = rho & 3;
+  return 16 * (q >> 1) + 8 * h + 4 * (q & 1) + i;
+}
+std::vector<half_t> frag_pack(const half_t* rows, int Kpad, const std::vector<std::pair<int, int>>& frags, bool operand) {
+  std::vector<half_t> out(frags.size() * 512);
+  for (size_t f = 0; f < frags.size(); ++f)
+    for (int lane = 0; lane < 64; ++lane) {
+      const half_t* src = rows + (size_t)(frags[f].first + frag_row(lane & 31, operand)) * Kpad + frags[f].second + 8 * (lane >> 5);
+      for (int j = 0; j < 8; ++j) out[(f * 64 + lane) * 8 + j] = src[j];
+    }
+  return out;
+}
+// the fragment lists of the kernels, by conv shape (empty = none of them takes this conv)
+std::vector<std::pair<int, int>> frag_list(int k, int cin, int cout) {
+  std::vector<std::pair<int, int>> f;
+  if (k == 3 && cin == 64 && cout == 64) {                      // conv3x3_c64r: [channel block m][36 slices]
+    for (int m = 0; m < 2; ++m)
+      for (int s = 0; s < 36; ++s) f.push_back({32 * m, 16 * s});
+  } else if (k == 3 && cin == 128 && cout == 128) {             // conv3x3_c128r: [m][input-channel half][tap][slice]
+    for (int m = 0; m < 4; ++m)
+      for (int kh = 0; kh < 2; ++kh)
+        for (int tap = 0; tap < 9; ++tap)
+          for (int s = 0; s < 4; ++s) f.push_back({32 * m, 128 * tap + 64 * kh + 16 * s});
+  } else if (k == 3 && cin == 32 && cout == 32) {               // c2f_c32: 18 slices
+    for (int s = 0; s < 18; ++s) f.push_back({0, 16 * s});
+  } else if (k == 1 && (cin == 128 || cin == 192 || cin == 256 || cin == 384 || cin == 512) && cout % 128 == 0 && cout <= 512) {
+    for (int cb = 0; cb < cout / 32; ++cb)                       // conv1x1_wreg: [channel block][K / 16 slices]
+      for (int s = 0; s < cin / 16; ++s) f.push_back({32 * cb, 16 * s});
+  }
+  return f;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1048,6 +1103,10 @@ void m355_destroy(m355_engine* e) {
     if (p.w) (void)hipFree(p.w);
     if (p.bias) (void)hipFree(p.bias);
     if (p.stem_w) (void)hipFree(p.stem_w);
+    if (p.wf) (void)hipFree(p.wf);
+    if (p.wf2) (void)hipFree(p.wf2);
+    if (p.w2) (void)hipFree(p.w2);
+    if (p.bias2) (void)hipFree(p.bias2);
   }
   if (e->raw) (void)hipFree(e->raw);
   if (e->zero) (void)hipFree(e->zero);
@@ -1179,6 +1238,19 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     HIP_TRY(e, hipMemcpy(p.w + (size_t)row0 * p.Kpad, rows.data(), rows.size() * sizeof(half_t),
                          hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias + row0, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
+    if (p.logical.size() == 1 && !p.diag && row0 == 0) {          // fragment-ordered copies for the weights-in-registers kernels
+      const auto fl = frag_list(ci.k, ci.cin, ci.cout);
+      if (!fl.empty()) {
+        const auto fp = frag_pack(rows.data(), p.Kpad, fl, false);
+        if (!p.wf) HIP_TRY(e, hipMalloc((void**)&p.wf, fp.size() * sizeof(half_t)));
+        HIP_TRY(e, hipMemcpy(p.wf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+        if (ci.k == 3 && ci.cin == 32) {
+          const auto fo = frag_pack(rows.data(), p.Kpad, fl, true);
+          if (!p.wf2) HIP_TRY(e, hipMalloc((void**)&p.wf2, fo.size() * sizeof(half_t)));
+          HIP_TRY(e, hipMemcpy(p.wf2, fo.data(), fo.size() * sizeof(half_t), hipMemcpyHostToDevice));
+        }
+      }
+    }
   }
   e->conv_loaded[idx] = true;
   return M355_OK;
@@ -1251,7 +1323,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         ConvArgs a{};
         a.x = ti.p + op.in.off; a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C;
         a.Hi = ti.H; a.Wi = ti.W; a.Cin = p.cin;
-        a.w = p.w; a.Kpad = p.Kpad; a.bias = p.bias;
+        a.w = p.w; a.Kpad = p.Kpad; a.bias = p.bias; a.wf = p.wf;
         a.zero = e->zero;
         a.act = p.act;
         if (op.kind == OP_CONVT) {
@@ -1318,6 +1390,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
              : (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
              : (op.tile == TILE_C64R) ? launch_conv3x3_c64r(a, s)
              : (op.tile == TILE_C128R) ? launch_conv3x3_c128r(a, s)
+             : (op.tile == TILE_W1) ? launch_conv1x1_wreg(a, s)
              : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
                                     : (op.tile == TILE_SLAB ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, op.tile, s)));
         break;
@@ -1329,7 +1402,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         C2fC32Args a{};
         a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C; a.H = ti.H; a.W = ti.W; a.B = Bq;
         a.x = ti.p + op.in.off + b0 * a.x_bstride;
-        a.wa = pa.w; a.wb = pb.w; a.wc = pc.w; a.kpad_a = pa.Kpad; a.kpad_b = pb.Kpad; a.kpad_c = pc.Kpad;
+        a.wa = pa.w; a.wb = pb.w; a.wc = pc.w; a.waf = pa.wf; a.wbf = pb.wf2; a.kpad_a = pa.Kpad; a.kpad_b = pb.Kpad; a.kpad_c = pc.Kpad;
         a.ba = pa.bias; a.bb = pb.bias; a.bc = pc.bias;
         a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
         a.y = to.p + op.out.off + b0 * a.y_bstride;
@@ -1525,9 +1598,18 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   HIP_TRYG(hipMemset(dz, 0, 256));
   HIP_TRYG(hipMemcpy(dw, rows.data(), rows.size() * sizeof(half_t), hipMemcpyHostToDevice));
   HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  half_t* dwf = nullptr;
+  if (!transposed) {
+    const auto fl = frag_list(k, cin, cout);
+    if (!fl.empty()) {
+      const auto fp = frag_pack(rows.data(), Kpad, fl, false);
+      HIP_TRYG(hipMalloc((void**)&dwf, fp.size() * sizeof(half_t)));
+      HIP_TRYG(hipMemcpy(dwf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    }
+  }
   ConvArgs a{};
   a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * cin; a.ldx = cin; a.Hi = H; a.Wi = W; a.Cin = cin;
-  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = act; a.out_f32 = out_f32; a.w_rows = cout_pad;
+  a.w = dw; a.Kpad = Kpad; a.bias = db; a.zero = dz; a.act = act; a.out_f32 = out_f32; a.w_rows = cout_pad; a.wf = dwf;
   a.y = d_y;
   if (transposed) {
     a.ksize = 1; a.stride = 1; a.pad = 0; a.Ho = H; a.Wo = W; a.Cout = 4 * cout; a.convt_co = cout;
@@ -1552,6 +1634,7 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   for (int rep = 0; rep < (a.dbg ? 5 : 1); ++rep)
     rc = (force_tile >= 0 && (force_tile & 0xff) == TILE_C64R) ? launch_conv3x3_c64r(a, s)
          : (force_tile >= 0 && (force_tile & 0xff) == TILE_C128R) ? launch_conv3x3_c128r(a, s)
+         : (force_tile >= 0 && (force_tile & 0xff) == TILE_W1) ? launch_conv1x1_wreg(a, s)
          : (force_tile >= 0 && (force_tile & 0xff) == TILE_C32)
              ? launch_conv3x3_c32(a, s)
              : ((force_tile >= 0 && (force_tile & 0xff) >= TILE_HALO) ? launch_conv3x3_halo(a, (force_tile & 0xff) - TILE_HALO, s)
@@ -1565,6 +1648,7 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   }
   if (d_st) (void)hipFree(d_st);
   (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dz);
+  if (dwf) (void)hipFree(dwf);
   if (rc != 0) return set_err(M355_ERR_HIP, "conv launch failed: " + std::to_string(rc));
   if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("conv kernel: ") + hipGetErrorString(se));
   return M355_OK;
@@ -1599,14 +1683,24 @@ int m355_c2f_c32_fwd(const void* d_x, int B, int H, int W, const float* h_wa, co
   HIP_TRYG(hipMemcpy(dw + na, rb.data(), nb * sizeof(half_t), hipMemcpyHostToDevice));
   HIP_TRYG(hipMemcpy(dw + na + nb, rc_.data(), ncw * sizeof(half_t), hipMemcpyHostToDevice));
   HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  half_t* dfr = nullptr;
+  {
+    const auto fl = frag_list(3, 32, 32);
+    auto fa = frag_pack(ra.data(), kp3, fl, false);
+    const auto fb = frag_pack(rb.data(), kp3, fl, true);
+    fa.insert(fa.end(), fb.begin(), fb.end());
+    HIP_TRYG(hipMalloc((void**)&dfr, fa.size() * sizeof(half_t)));
+    HIP_TRYG(hipMemcpy(dfr, fa.data(), fa.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  }
   C2fC32Args a{};
   a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * 64; a.ldx = 64; a.H = H; a.W = W; a.B = B;
   a.wa = dw; a.wb = dw + na; a.wc = dw + na + nb; a.kpad_a = kp3; a.kpad_b = kp3; a.kpad_c = kp1;
+  a.waf = dfr; a.wbf = dfr + 18 * 512;
   a.ba = db; a.bb = db + 32; a.bc = db + 64;
   a.y = (half_t*)d_y; a.y_bstride = (long)H * W * 64; a.ldy = 64; a.shortcut = shortcut;
   const int rc = launch_c2f_c32(a, s);
   const hipError_t se = hipStreamSynchronize(s);
-  (void)hipFree(dw); (void)hipFree(db);
+  (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dfr);
   if (rc != 0) return set_err(M355_ERR_HIP, "c2f_c32 launch failed: " + std::to_string(rc));
   if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("c2f_c32 kernel: ") + hipGetErrorString(se));
   return M355_OK;

@@ -123,8 +123,8 @@ def test_yolo_facade_offline_behaviour(tmp_path):
         YOLO("yolov9c-seg.pt")                                  # yolo_seg_train.py:8 -- would download upstream
     v9 = YOLO("yolov9c-seg.yaml")                               # yolo_seg_train.py:7 -- row N4: the graph exists now
     assert v9.scale == "9c" and v9.nc == 80 and v9.info()[1] == 27897120    # the published yolov9c-seg parameter count
-    with pytest.raises(NotImplementedError, match="training graph"):
-        v9.train(data="data-seg.yaml", epochs=1)
+    with pytest.raises((RuntimeError, FileNotFoundError)):     # its training graph exists too (round 3): on this CPU box the call
+        v9.train(data="data-seg.yaml", epochs=1)                # gets as far as "needs a gfx950 GPU" / the missing dataset
     with pytest.raises(NotImplementedError):
         YOLO("yolo11n-seg.yaml")                                # detect / other families: still next rows
     m = YOLO("yolov8n-seg.yaml")

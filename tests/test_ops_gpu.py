@@ -87,6 +87,14 @@ CONV_CASES = [
     (1, 8, 8, 128, 128, 3, 1, 1, False, 31),        # one tile: all four borders at once
     (3, 24, 16, 128, 128, 3, 1, 0, True, 31),       # no activation, residual
     (48, 40, 40, 128, 128, 3, 1, 1, False, 31),     # 1200 tiles over 256 blocks: 4 or 5 tiles per block
+    # 1x1 with the weights in registers (32, conv1x1_wreg.hip): K <= 512, Cout % 128 == 0, flat pixel axis
+    (2, 80, 80, 256, 128, 1, 1, 1, False, 32),      # C2f.cv2 at 80 x 80: 128-pixel tiles, four channel blocks x two pixel halves
+    (1, 80, 80, 192, 128, 1, 1, 1, False, 32),      # K = 192: 3-bit chunk swizzle, three tile buffers
+    (2, 40, 40, 256, 256, 1, 1, 1, False, 32),      # eight channel blocks, 64-pixel tiles
+    (3, 40, 40, 384, 256, 1, 1, 0, False, 32),      # K = 384, no activation, two tile buffers
+    (4, 20, 20, 512, 512, 1, 1, 1, False, 32),      # two channel tiles of 256: blocks cross the channel-tile boundary
+    (24, 40, 40, 512, 256, 1, 1, 1, False, 32),     # 600 tiles over 256 blocks: 2 or 3 tiles per block, K = 512
+    (2, 8, 8, 128, 128, 1, 1, 1, False, 32),        # one 128-pixel tile, K = 128
     # slab kernel for narrow maps (25): R full-width rows x 64 channels, linear pixel groups
     (2, 20, 20, 256, 256, 3, 1, 1, True, 25),       # the 20x20 C2f layers: two slabs of 10 rows, 12.5 groups
     (3, 20, 20, 512, 224, 3, 1, 0, False, 25),      # fused head-level convs: ragged channel tile (224 = 3 x 64 + 32)
