@@ -74,6 +74,7 @@ struct ConvArgs {
   // f at halves [f * 512, f * 512 + 512), lane-linear 16 bytes = the A operand of one 32x32x16 MFMA.  nullptr: the kernels
   // gather the fragments from `w` (64 scattered 16-byte loads per fragment).
   const half_t* wf;
+  const half_t* wf2;   // the same for `w2` (proto_phase_wreg.hip: the eight fragments of proto.cv3)
   int bias_lds;        // set by the implicit-GEMM launcher: this many bias floats are staged in LDS behind the stages (0: none)
 };
 
@@ -131,6 +132,9 @@ int launch_conv3x3_c128r(const ConvArgs& a, hipStream_t s);
 // 1x1, K <= 512, Cout % 128 == 0: weights in registers, persistent (conv1x1_wreg.hip)
 bool conv1x1_wreg_ok(const ConvArgs& a);
 int launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
+// the composed Proto launch (phase conv + proto.cv3) with the weights in registers, one phase per block (proto_phase_wreg.hip)
+bool proto_phase_wreg_ok(const ConvArgs& a);
+int launch_proto_phase_wreg(const ConvArgs& a, hipStream_t s);
 // Cin = Cout = 32, weights-stationary persistent halo kernel (conv3x3_c32.hip)
 bool conv3x3_c32_ok(const ConvArgs& a);
 int launch_conv3x3_c32(const ConvArgs& a, hipStream_t s);

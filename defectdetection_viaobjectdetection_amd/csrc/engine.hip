@@ -62,6 +62,7 @@ struct Op {
   int tile = -1;
   int decode = 0;         // head output conv that also decodes its rows into the prediction tensor (no OP_DECODE launch)
   int s2c32 = 0;          // conv 3x3/s2 (32 -> 64) + 1x1 (64 -> 64) on the dedicated patch kernel (conv3x3_s2c32.hip)
+  int protor = 0;         // OP_PHASE + proto.cv3 on the weights-in-registers kernel (proto_phase_wreg.hip)
   int stemfuse = -1;      // >= 0: index of the stem op this launch also computes (conv_stem_s2c32.hip); that op is then skipped
   bool fused_away = false;
   // stream lanes (plan_lanes): lane 0 is the caller's stream, lanes >= 1 are engine-owned side streams
@@ -935,6 +936,10 @@ void annotate_ops(m355_engine* e) {
         if (p.l3 >= 0) {
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<128x128,k2,phase+1x1>");
           snprintf(op.layer, sizeof(op.layer), "model.22.proto.upsample+cv2+cv3");
+          if (p.cin == 128 && p.cout == 128 && p.cout2 == 32 && ti.H % 8 == 0 && ti.W % 16 == 0 && !getenv("M355_NO_PROTOR")) {
+            op.protor = 1;
+            snprintf(op.kernel, sizeof(op.kernel), "proto_phase_wreg<8x16px>");
+          }
         }
         op.wbytes = (double)p.cout_pad * p.Kpad * 2;
         break;
@@ -1149,6 +1154,13 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     for (size_t i = 0; i < r2.size(); ++i) r2[i] = (half_t)w[i];
     HIP_TRY(e, hipMemcpy(p.w2, r2.data(), r2.size() * sizeof(half_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias2, bias, p.cout2 * sizeof(float), hipMemcpyHostToDevice));
+    if (p.composed && p.cout2 == 32 && p.cout == 128) {   // proto.cv3 as eight MFMA fragments (proto_phase_wreg.hip)
+      std::vector<std::pair<int, int>> fl;
+      for (int s = 0; s < 8; ++s) fl.push_back({0, 16 * s});
+      const auto fp = frag_pack(r2.data(), p.cout, fl, false);
+      if (!p.wf2) HIP_TRY(e, hipMalloc((void**)&p.wf2, fp.size() * sizeof(half_t)));
+      HIP_TRY(e, hipMemcpy(p.wf2, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    }
     e->conv_loaded[idx] = true;
     return M355_OK;
   }
@@ -1211,6 +1223,15 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
         }
     HIP_TRY(e, hipMemcpy(p.w, rows.data(), rows.size() * sizeof(half_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias, btab.data(), btab.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (n == 128) {   // fragment-ordered copy [phase][channel block][32 slices] for proto_phase_wreg.hip
+      std::vector<std::pair<int, int>> fl;
+      for (int q = 0; q < 4; ++q)
+        for (int mb = 0; mb < 4; ++mb)
+          for (int s = 0; s < 32; ++s) fl.push_back({q * 128 + 32 * mb, 16 * s});
+      const auto fp = frag_pack(rows.data(), p.Kpad, fl, false);
+      if (!p.wf) HIP_TRY(e, hipMalloc((void**)&p.wf, fp.size() * sizeof(half_t)));
+      HIP_TRY(e, hipMemcpy(p.wf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    }
     return M355_OK;
   }
   if (ci.cin == 3) {  // stem: [cout][32] fp16, k = (kh*3+kw)*3+c; 1/255 is applied in the kernel's epilogue
@@ -1313,7 +1334,9 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           a.y = to.p + op.out.off; a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
         }
         a.M = Bq * a.Ho * a.Wo;
-        rc = launch_conv_igemm(a, op.tile, s);
+        a.wf = p.wf; a.wf2 = p.wf2;
+        if (b0) a.x += b0 * a.x_bstride;
+        rc = (op.protor && proto_phase_wreg_ok(a)) ? launch_proto_phase_wreg(a, s) : launch_conv_igemm(a, op.tile, s);
         break;
       }
       case OP_CONV:
@@ -1390,7 +1413,8 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
              : (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
              : (op.tile == TILE_C64R) ? launch_conv3x3_c64r(a, s)
              : (op.tile == TILE_C128R) ? launch_conv3x3_c128r(a, s)
-             : (op.tile == TILE_W1) ? launch_conv1x1_wreg(a, s)
+             // (the pixel count of THIS call may not be a multiple of the kernel's tile although max_batch's was: im2col then)
+             : (op.tile == TILE_W1) ? (conv1x1_wreg_ok(a) ? launch_conv1x1_wreg(a, s) : launch_conv_igemm(a, TILE_AUTO, s))
              : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
                                     : (op.tile == TILE_SLAB ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, op.tile, s)));
         break;

@@ -115,3 +115,44 @@ def test_engine_with_the_fused_block_equals_the_three_launches(cuda_device):
         assert q(dp[..., 4], .99) <= 1e-3 and q(dp[..., :4], .99) <= 0.15 and q(dp[..., :4], .999) <= 0.45
         assert float(dp[..., 4].max()) <= 5e-3 and float(dp[..., :4].max()) <= 1.0
         assert float((outs[True][1] - outs[False][1]).norm() / outs[False][1].norm()) <= 2e-3
+
+
+@pytest.mark.parametrize("size,batch", [(320, 3), (640, 2)])
+def test_weights_in_registers_kernels_equal_the_im2col_forms(cuda_device, size, batch):
+    """The round-3 kernels that keep their weights in registers -- conv1x1_wreg (1x1, K <= 512), proto_phase_wreg (the composed
+    Proto launch) and, opt-in, conv3x3_c64r / conv3x3_c128r -- against the im2col / halo kernels they replace, whole network,
+    same weights: same rounding points, different fp32 summation order only."""
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from defectdetection_viaobjectdetection_amd.synthetic import synthetic_bscans
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(batch, size, size, seed=6)).to(cuda_device)
+    variants = {"default": {}, "old": {"M355_NO_W1": "1", "M355_NO_PROTOR": "1", "M355_NO_C2F32": "1"},
+                "all": {"M355_C64R": "1", "M355_C128R": "1"}}
+    outs, kern = {}, {}
+    for name, env in variants.items():
+        os.environ.update(env)
+        try:
+            eng = SegEngine("s", 1, (size, size), max_batch=batch)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        eng.load_state_dict(sd)
+        kern[name] = sorted({o["kernel"] for o in eng.op_infos()})
+        preds, protos = eng.forward(imgs)
+        torch.cuda.synchronize()
+        outs[name] = (preds.clone(), protos.float().clone())
+        eng.close()
+    assert any(k.startswith("conv1x1_wreg") for k in kern["default"])
+    assert not any(k.startswith(("conv1x1_wreg", "proto_phase_wreg", "c2f_c32")) for k in kern["old"])
+    if size == 640:       # (their tiles need 80 x 80 / 40 x 40 maps that are multiples of 8 x 16 / 8 x 8)
+        assert any(k.startswith("proto_phase_wreg") for k in kern["all"])
+        assert any(k.startswith("conv3x3_c64r") for k in kern["all"]) and any(k.startswith("conv3x3_c128r") for k in kern["all"])
+    q = lambda t, f: float(t.flatten().kthvalue(max(1, int(t.numel() * f)))[0])
+    for name in ("default", "all"):
+        dp = (outs[name][0] - outs["old"][0]).abs()
+        rel = float((outs[name][1] - outs["old"][1]).norm() / outs["old"][1].norm())
+        print(f"{size} {name} vs old: score p99 {q(dp[..., 4], .99):.2e} max {float(dp[..., 4].max()):.2e}; box px p99 {q(dp[..., :4], .99):.3f} "
+              f"max {float(dp[..., :4].max()):.3f}; protos rel-L2 {rel:.2e}")
+        assert q(dp[..., 4], .99) <= 1e-3 and q(dp[..., :4], .99) <= 0.15 and q(dp[..., :4], .999) <= 0.45
+        assert float(dp[..., 4].max()) <= 5e-3 and float(dp[..., :4].max()) <= 1.3 and rel <= 2e-3

@@ -4,7 +4,8 @@ coalesced streaming reads -> doubled; WRITE_SIZE is exact for 16-byte-per-lane s
 import csv, json, re, sys, collections
 
 LABELS = {
-    "c2f_c32_kernel": "c2f_c32<8x16px>",
+    "c2f_c32_kernel": "c2f_c32<8x16px>", "proto_phase_wreg_kernel": "proto_phase_wreg<8x16px>",
+    "conv3x3_c64r_kernel": "conv3x3_c64r<64ch,8x16px>", "conv3x3_c128r_kernel": "conv3x3_c128r<128ch,8x8px>",
     "conv3x3_halo_kernel<4, 4, 2, 2>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 4>": "conv3x3_halo<64ch>",
     "conv3x3_halo_kernel<4, 4, 2, 4>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 8>": "conv3x3_halo<64ch>",
     "conv_igemm_kernel<4, 4, 2, 2, 3>": "conv_igemm<128x128,k3>", "conv_igemm_kernel<4, 4, 2, 2, 1>": "conv_igemm<128x128,k1>",
@@ -25,6 +26,9 @@ MANGLED = {"ILi4ELi4ELi2ELi2EEEvNS_8ConvArgsEiiii": "conv3x3_halo<128ch>", "ILi4
 def label(name):
     # conv_igemm_kernel<MT, NT, WCH, WPX, KS, EPI>: the epilogue selector (0 plain, 1 decode, 2 phase + 1x1) is not part of the label
     name = re.sub(r"(conv_igemm_kernel<\d+, \d+, \d+, \d+, \d+), \d+>", r"\1>", name)
+    mw = re.search(r"conv1x1_wreg_kernel<(\d+), (\d+)>", name)
+    if mw:
+        return f"conv1x1_wreg<K{mw.group(1)},{int(mw.group(2)) * 32}ch>"
     for k, v in LABELS.items():
         if k in name:
             return v
