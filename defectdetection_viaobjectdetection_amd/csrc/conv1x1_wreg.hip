@@ -105,18 +105,19 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)a.M * a.ldx * 2), 0x00020000);
   // ---- activation tile pieces: wave w owns pieces g = w + 8 i; lane-linear chunk id c = 64 g + lane = (pixel, slot)
-  int prel[C::P_IT];
-#pragma unroll
-  for (int i = 0; i < C::P_IT; ++i) {
-    const int cid = 64 * (wave + NWAVES * i) + lane;
-    const int px = cid / C::NCH, slot = cid - px * C::NCH;
-    const int cc = slot ^ (px & C::SWM);
-    prel[i] = (px * a.ldx + cc * 8) * 2;
-  }
+  // (the per-piece offsets are rebuilt from mbcnt at every issue: held in registers across the K loop they are spilled in the
+  // K = 512 form, and a scratch reload waits on vmcnt(0), i.e. on the stores of the tile just finished)
   auto issue_tile = [&](int p0, int buf) __attribute__((always_inline)) {
     const int soff = p0 * a.ldx * 2;
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
 #pragma unroll
-    for (int i = 0; i < C::P_IT; ++i) dma16(rs_x, prel[i], soff, smem + buf * C::TILE_BYTES + (wave + NWAVES * i) * 1024);
+    for (int i = 0; i < C::P_IT; ++i) {
+      const int cid = 64 * (wave + NWAVES * i) + ln;
+      const int px = cid / C::NCH, slot = cid - px * C::NCH;
+      const int cc = slot ^ (px & C::SWM);
+      dma16(rs_x, (px * a.ldx + cc * 8) * 2, soff, smem + buf * C::TILE_BYTES + (wave + NWAVES * i) * 1024);
+    }
   };
   // ---- fragment offsets: pixel (64 ph + 32 pb + n) of the tile, chunk 2 s + h
   int offp[2], swz[2];

@@ -115,25 +115,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128r_kernel(const ConvArgs a,
   const int img_stride = (int)a.x_bstride * 2;
 
   // ---- patch pieces: wave w owns pieces g = w + 8 i (4 LDS rows each); lane = (row 4 g + lane / 16, chunk slot lane % 16)
-  int prel[P_IT], prc[P_IT];
-#pragma unroll
-  for (int i = 0; i < P_IT; ++i) {
-    const int R = 4 * (wave + NWAVES * i) + (lane >> 4);
-    const int pr = R / PP, pc = R - pr * PP;
-    const int cc = (lane & 15) ^ (((pr & 3) << 2) | (pc & 3));
-    prel[i] = ((pr * W + pc) * a.ldx + cc * 8) * 2;
-    prc[i] = pr | (pc << 8);
-  }
   auto issue_patch = [&](int tb, int y0, int x0, int buf) __attribute__((always_inline)) {
     const int origin = (((y0 - 1) * W + (x0 - 1)) * a.ldx) * 2;
     const bool interior = y0 >= 1 && y0 + TH + 1 <= H && x0 >= 1 && x0 + TW + 1 <= W;
+    // (piece geometry is rebuilt from mbcnt per issue: kept live across the K loop it is spilled, and a scratch reload waits on
+    // vmcnt, i.e. on the DMA issued just before it -- and breaks the counted waits below)
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int r0 = 4 * wave + (ln >> 4), slot = ln & 15;
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
       const int g = wave + NWAVES * i;
       if (g < NPIECES) {
-        const int yy = y0 - 1 + (prc[i] & 255), xx = x0 - 1 + (prc[i] >> 8);
+        const int R = r0 + 4 * NWAVES * i;
+        const int pr = (R * 6554) >> 16, pc = R - pr * PP;           // R / 10, R % 10 (exact for R < 200)
+        const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
         const bool ok = interior || ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W);
-        dma16(rs_x, ok ? origin + prel[i] : (int)0x80000000, tb * img_stride, smem + buf * PATCH_BYTES + g * 1024);
+        const int rel = ((pr * W + pc) * a.ldx + ((slot ^ (((pr & 3) << 2) | (pc & 3))) << 3)) * 2;
+        dma16(rs_x, ok ? origin + rel : (int)0x80000000, tb * img_stride, smem + buf * PATCH_BYTES + g * 1024);
       }
     }
   };
@@ -155,8 +154,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128r_kernel(const ConvArgs a,
   char* const xch = smem + XCH_OFF;
   char* const stg = smem + STG_OFF + wave * 2048;
   const int partner = wave ^ 4;
-  const int st_w0 = n * 64 + (((2 * h) ^ ((n >> 1) & 3)) << 4), st_w1 = n * 64 + (((2 * h + 1) ^ ((n >> 1) & 3)) << 4);
-  const int st_p = lane >> 2, st_k = lane & 3;
 
   int tbi[3], ty0[3], tx0[3];
   bool have[3];
@@ -233,9 +230,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128r_kernel(const ConvArgs a,
 #pragma unroll
         for (int s = 0; s < 4; ++s) acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w8[s], fr[pb][s], acc[pb], 0, 0, 0);
     }
+    // (lane-derived values of the epilogue are rebuilt from mbcnt here: kept live across the K loop they are spilled, and a
+    // scratch reload waits on vmcnt(0) = drains the patch prefetch and the previous tile's stores)
+    int e_lane;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(e_lane));
+    const int e_n = e_lane & 31, e_h = e_lane >> 5, e_prow0 = e_n >> 3, e_pcol0 = e_n & 7;
+    const int e_st_w0 = e_n * 64 + (((2 * e_h) ^ ((e_n >> 1) & 3)) << 4), e_st_w1 = e_n * 64 + (((2 * e_h + 1) ^ ((e_n >> 1) & 3)) << 4);
+    const int e_st_p = e_lane >> 2, e_st_k = e_lane & 3;
     // ---- exchange: give the partner the partial sum of ITS block, take the partner's partial sum of mine
     {
-      float* const mine = (float*)(xch + wave * 4096) + lane * 4;
+      float* const mine = (float*)(xch + wave * 4096) + e_lane * 4;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         float4v u;
@@ -247,8 +251,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128r_kernel(const ConvArgs a,
     // (loaded here, not at the top of the tile: eight registers the K loop does not have)
     half8 res0 = (half8)(half_t)0.f, res1 = res0;
     if (a.res) {
-      const long pix = (long)(ty0[0] + 4 * KH + prow0) * W + tx0[0] + pcol0;
-      const half_t* rp = a.res + (long)tbi[0] * a.r_bstride + pix * a.ldr + 32 * m + 16 * h;
+      const long pix = (long)(ty0[0] + 4 * KH + e_prow0) * W + tx0[0] + e_pcol0;
+      const half_t* rp = a.res + (long)tbi[0] * a.r_bstride + pix * a.ldr + 32 * m + 16 * e_h;
       res0 = *(const half8*)rp;
       res1 = *(const half8*)(rp + 8);
     }
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128r_kernel(const ConvArgs a,
     float16v fin = acc[KH];
     {
 #pragma clang fp contract(off)
-      const float* const theirs = (const float*)(xch + partner * 4096) + lane * 4;
+      const float* const theirs = (const float*)(xch + partner * 4096) + e_lane * 4;
 #pragma unroll
       for (int qd = 0; qd < 4; ++qd) {
         const float4v u = *(const float4v*)(theirs + qd * 256);
@@ -278,16 +282,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c128r_kernel(const ConvArgs a,
         o1[j] = m355_to_half(v1);
       }
     }
-    *(half8*)(stg + st_w0) = o0;
-    *(half8*)(stg + st_w1) = o1;
+    *(half8*)(stg + e_st_w0) = o0;
+    *(half8*)(stg + e_st_w1) = o1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     {
       half_t* const yb = (half_t*)a.y + (long)tbi[0] * a.y_bstride + ((long)(ty0[0] + 4 * KH) * W + tx0[0]) * a.ldy + 32 * m;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {      // staged pixels 16 i .. 16 i + 15 = block rows 2 i, 2 i + 1 (8 columns each)
-        const int p = 16 * i + st_p;
-        const half8 v = *(const half8*)(stg + p * 64 + ((st_k ^ ((p >> 1) & 3)) << 4));
-        *(half8*)(yb + ((long)(p >> 3) * W + (p & 7)) * a.ldy + st_k * 8) = v;
+        const int p = 16 * i + e_st_p;
+        const half8 v = *(const half8*)(stg + p * 64 + ((e_st_k ^ ((p >> 1) & 3)) << 4));
+        *(half8*)(yb + ((long)(p >> 3) * W + (p & 7)) * a.ldy + e_st_k * 8) = v;
       }
     }
     // the patch of tile it + 1 has landed for this wave: everything older than this iteration's own pieces and stores

@@ -117,7 +117,7 @@ def test_engine_with_the_fused_block_equals_the_three_launches(cuda_device):
         assert float((outs[True][1] - outs[False][1]).norm() / outs[False][1].norm()) <= 2e-3
 
 
-@pytest.mark.parametrize("size,batch", [(320, 3), (640, 2)])
+@pytest.mark.parametrize("size,batch", [(320, 4), (640, 2)])
 def test_weights_in_registers_kernels_equal_the_im2col_forms(cuda_device, size, batch):
     """The round-3 kernels that keep their weights in registers -- conv1x1_wreg (1x1, K <= 512), proto_phase_wreg (the composed
     Proto launch) and, opt-in, conv3x3_c64r / conv3x3_c128r -- against the im2col / halo kernels they replace, whole network,
