@@ -132,6 +132,9 @@ int launch_conv3x3_c128r(const ConvArgs& a, hipStream_t s);
 // 1x1, K <= 512, Cout % 128 == 0: weights in registers, persistent (conv1x1_wreg.hip)
 bool conv1x1_wreg_ok(const ConvArgs& a);
 int launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
+// 3x3 / s2 (64 -> 128) + 1x1 (128 -> 128): model.3 + model.4.cv1 of the s scale, 3x3 weights in registers (conv3x3_s2c64.hip)
+bool conv_s2c64_cv1_ok(const ConvArgs& a);
+int launch_conv_s2c64_cv1(const ConvArgs& a, hipStream_t s);
 // the composed Proto launch (phase conv + proto.cv3) with the weights in registers, one phase per block (proto_phase_wreg.hip)
 bool proto_phase_wreg_ok(const ConvArgs& a);
 int launch_proto_phase_wreg(const ConvArgs& a, hipStream_t s);

@@ -62,6 +62,7 @@ struct Op {
   int tile = -1;
   int decode = 0;         // head output conv that also decodes its rows into the prediction tensor (no OP_DECODE launch)
   int s2c32 = 0;          // conv 3x3/s2 (32 -> 64) + 1x1 (64 -> 64) on the dedicated patch kernel (conv3x3_s2c32.hip)
+  int s2c64 = 0;          // conv 3x3/s2 (64 -> 128) + 1x1 (128 -> 128) on the weights-in-registers kernel (conv3x3_s2c64.hip)
   int protor = 0;         // OP_PHASE + proto.cv3 on the weights-in-registers kernel (proto_phase_wreg.hip)
   int stemfuse = -1;      // >= 0: index of the stem op this launch also computes (conv_stem_s2c32.hip); that op is then skipped
   bool fused_away = false;
@@ -913,6 +914,11 @@ void annotate_ops(m355_engine* e) {
             op.s2c32 = 1;
             snprintf(op.kernel, sizeof(op.kernel), "conv3x3_s2c32<8x16px>+1x1");
           }
+          if (p.k == 3 && p.stride == 2 && p.cin == 64 && p.cout == 128 && p.cout2 == 128 && Ho % 8 == 0 && Wo % 8 == 0 &&
+              !getenv("M355_NO_S2C64")) {
+            op.s2c64 = 1;
+            snprintf(op.kernel, sizeof(op.kernel), "conv3x3_s2c64<8x8px>+1x1");
+          }
           snprintf(op.layer, sizeof(op.layer), "%s+%s", e->convs[p.logical[0]].name, e->convs[p.l3].name);
           op.flops += 2.0 * Ho * Wo * (double)p.cout * p.cout2;
         }
@@ -1044,6 +1050,9 @@ std::vector<std::pair<int, int>> frag_list(int k, int cin, int cout) {
       for (int kh = 0; kh < 2; ++kh)
         for (int tap = 0; tap < 9; ++tap)
           for (int s = 0; s < 4; ++s) f.push_back({32 * m, 128 * tap + 64 * kh + 16 * s});
+  } else if (k == 3 && cin == 64 && cout == 128) {              // conv3x3_s2c64: [channel block m][36 slices]
+    for (int m = 0; m < 4; ++m)
+      for (int s = 0; s < 36; ++s) f.push_back({32 * m, 16 * s});
   } else if (k == 3 && cin == 32 && cout == 32) {               // c2f_c32: 18 slices
     for (int s = 0; s < 18; ++s) f.push_back({0, 16 * s});
   } else if (k == 1 && (cin == 128 || cin == 192 || cin == 256 || cin == 384 || cin == 512) && cout % 128 == 0 && cout <= 512) {
@@ -1161,6 +1170,14 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
       if (!p.wf2) HIP_TRY(e, hipMalloc((void**)&p.wf2, fp.size() * sizeof(half_t)));
       HIP_TRY(e, hipMemcpy(p.wf2, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
     }
+    if (!p.composed && p.k == 3 && p.stride == 2 && p.cin == 64 && p.cout == 128 && p.cout2 == 128) {   // conv3x3_s2c64: [m][8 slices]
+      std::vector<std::pair<int, int>> fl;
+      for (int m = 0; m < 4; ++m)
+        for (int s = 0; s < 8; ++s) fl.push_back({32 * m, 16 * s});
+      const auto fp = frag_pack(r2.data(), p.cout, fl, false);
+      if (!p.wf2) HIP_TRY(e, hipMalloc((void**)&p.wf2, fp.size() * sizeof(half_t)));
+      HIP_TRY(e, hipMemcpy(p.wf2, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    }
     e->conv_loaded[idx] = true;
     return M355_OK;
   }
@@ -1259,7 +1276,7 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     HIP_TRY(e, hipMemcpy(p.w + (size_t)row0 * p.Kpad, rows.data(), rows.size() * sizeof(half_t),
                          hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias + row0, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
-    if (p.logical.size() == 1 && !p.diag && row0 == 0) {          // fragment-ordered copies for the weights-in-registers kernels
+    if ((p.logical.size() == 1 || (p.l3 >= 0 && !p.composed && idx == p.logical[0])) && !p.diag && row0 == 0) {   // fragment-ordered copies for the weights-in-registers kernels
       const auto fl = frag_list(ci.k, ci.cin, ci.cout);
       if (!fl.empty()) {
         const auto fp = frag_pack(rows.data(), p.Kpad, fl, false);
@@ -1390,7 +1407,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         }
         if (op.kind == OP_CONV && e->phys[op.conv].l3 >= 0) {   // following 1x1 conv in this launch's epilogue
           const PhysConv& pf = e->phys[op.conv];
-          a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2;
+          a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2; a.wf2 = pf.wf2;
         }
         a.tileq = knobs().static_tiles ? nullptr : e->tileq + 4 * oi;
         if (op.stemfuse >= 0) {
@@ -1410,6 +1427,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           if (rc != 0) break;
         }
         rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
+             : (op.s2c64 && conv_s2c64_cv1_ok(a)) ? launch_conv_s2c64_cv1(a, s)
              : (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
              : (op.tile == TILE_C64R) ? launch_conv3x3_c64r(a, s)
              : (op.tile == TILE_C128R) ? launch_conv3x3_c128r(a, s)

@@ -60,8 +60,8 @@ __device__ __forceinline__ void silu16(float16v& v) {
   for (int j = 0; j < 16; ++j) v[j] = v[j] * t[j];
 }
 
-__global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ntiles,
-                                                                 unsigned long long* stamps) {
+__global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ntiles, int sx, int sy,
+                                                                 int sb, unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -134,6 +134,8 @@ __global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs
 
   int t = vb, tb, y0, x0, ntb = 0, ny0 = 0, nx0 = 0;
   tile_of(t, tb, y0, x0);
+  // the walk in tile units, stepped with carries from here on (the scalar divisions of tile_of cost ~1 k cycles per tile)
+  int wb = tb, wy = y0 / TH, wx = x0 / TW;
   issue_patch(tb, y0, x0, 0);
   __builtin_amdgcn_s_waitcnt(0x0070);                  // (the builtin: the compiler does not re-wait for the weight loads in the loop)
   __builtin_amdgcn_s_barrier();
@@ -203,7 +205,12 @@ __global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs
     ++ntile;
     const bool more = t + nblk < ntiles;
     if (more) {                                        // the next tile's patch streams in under this tile's arithmetic
-      tile_of(t + nblk, ntb, ny0, nx0);
+      wx += sx;
+      if (wx >= tiles_x) { wx -= tiles_x; ++wy; }
+      wy += sy;
+      if (wy >= tiles_y) { wy -= tiles_y; ++wb; }
+      wb += sb;
+      ntb = wb; ny0 = wy * TH; nx0 = wx * TW;
       issue_patch(ntb, ny0, nx0, (it + 1) & 1);
     }
     PP_STAMP(0)   // tile decode + DMA issue
@@ -322,6 +329,8 @@ int launch_proto_phase_wreg(const ConvArgs& a, hipStream_t s) {
     if (slots < 4) slots = 4;
   }
   int grid = 4 * ntiles <= slots ? 4 * ntiles : slots;  // a multiple of 4: every phase gets the same number of blocks
+  const int step = grid >> 2;                          // tiles between two visits of a block (= blocks per phase)
+  const int sx = step % tiles_x, sy = (step / tiles_x) % tiles_y, sb = step / tiles_x / tiles_y;
   // diagnostic: M355_PROTOR_STAMPS=<file> -> per-wave section cycles of the LAST launch, written after a stream sync [sync]
   static const char* st_path = getenv("M355_PROTOR_STAMPS");
   static unsigned long long* d_st = nullptr;
@@ -329,7 +338,7 @@ int launch_proto_phase_wreg(const ConvArgs& a, hipStream_t s) {
     if (hipMalloc((void**)&d_st, (size_t)slots * NWAVES * 64) != hipSuccess) return -2;
     (void)hipMemset(d_st, 0, (size_t)slots * NWAVES * 64);
   }
-  hipLaunchKernelGGL(proto_phase_wreg_kernel, dim3(grid), dim3(64 * NWAVES), LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, d_st);
+  hipLaunchKernelGGL(proto_phase_wreg_kernel, dim3(grid), dim3(64 * NWAVES), LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, sx, sy, sb, d_st);
   if (st_path) {
     if (hipStreamSynchronize(s) != hipSuccess) return -2;
     const size_t nbytes = (size_t)grid * NWAVES * 64;
