@@ -132,6 +132,22 @@ int launch_conv3x3_c128r(const ConvArgs& a, hipStream_t s);
 // 1x1, K <= 512, Cout % 128 == 0: weights in registers, persistent (conv1x1_wreg.hip)
 bool conv1x1_wreg_ok(const ConvArgs& a);
 int launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);
+// The output convs of one head level + the decode of their rows in one launch (head_tail.hip): x = the level's 224-channel
+// branch tensor (64 box | 128 class | 32 coefficient channels), dense rows; wf = 18 MFMA fragments (box 2 x 4, class 8,
+// coefficients 2) of the block-diagonal weight matrix; bias = [64 | nc | nm]; preds = (B, A, 4 + nc + nm) fp32.
+struct HeadTailArgs {
+  const half_t* x;
+  int ldx;             // 224
+  long M;              // B * H * W pixels of the level
+  int HW, W;           // anchors of the level per image, grid width
+  float stride;
+  int A, level_off, nc, nm;
+  const half_t* wf;
+  const float* bias;
+  float* preds;
+};
+bool head_tail_ok(const HeadTailArgs& a);
+int launch_head_tail(const HeadTailArgs& a, hipStream_t s);
 // 3x3 / s2 (64 -> 128) + 1x1 (128 -> 128): model.3 + model.4.cv1 of the s scale, 3x3 weights in registers (conv3x3_s2c64.hip)
 bool conv_s2c64_cv1_ok(const ConvArgs& a);
 int launch_conv_s2c64_cv1(const ConvArgs& a, hipStream_t s);

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
   // K = 512 form, and a scratch reload waits on vmcnt(0), i.e. on the stores of the tile just finished)
   auto issue_tile = [&](int p0, int buf) __attribute__((always_inline)) {
     const int soff = p0 * a.ldx * 2;
+    const int npx = a.M - p0;                          // pixels of this tile inside the tensor (< TP only in the last pixel tile)
     int ln;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
 #pragma unroll
@@ -116,7 +117,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
       const int cid = 64 * (wave + NWAVES * i) + ln;
       const int px = cid / C::NCH, slot = cid - px * C::NCH;
       const int cc = slot ^ (px & C::SWM);
-      dma16(rs_x, (px * a.ldx + cc * 8) * 2, soff, smem + buf * C::TILE_BYTES + (wave + NWAVES * i) * 1024);
+      dma16(rs_x, px < npx ? (px * a.ldx + cc * 8) * 2 : (int)0x80000000, soff,
+            smem + buf * C::TILE_BYTES + (wave + NWAVES * i) * 1024);   // past the tensor: zeros
     }
   };
   // ---- fragment offsets: pixel (64 ph + 32 pb + n) of the tile, chunk 2 s + h
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
         for (int i = 0; i < 2; ++i) {
           const int p = 16 * i + st_p;
           const half8 v = *(const half8*)(stg + p * 64 + ((st_k ^ ((p >> 1) & 3)) << 4));
-          *(half8*)(yb + (long)(32 * pb + p) * a.ldy + st_k * 8) = v;
+          if (p0 + 64 * ph + 32 * pb + p < a.M) *(half8*)(yb + (long)(32 * pb + p) * a.ldy + st_k * 8) = v;
         }
       }
     }
@@ -215,7 +217,12 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
     if (C::NBUF == 3) {
       // the next tile (issued one iteration ago, or in the prologue) has landed for this wave: everything older than this
       // iteration's own pieces and its four stores
-      if (have2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::P_IT + 4) : "memory");
+      // (a partial last pixel tile may have issued fewer than four stores: its wait covers them too)
+      const bool partial = p0 + C::TP > a.M;
+      if (partial) {
+        if (have2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::P_IT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      } else if (have2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::P_IT + 4) : "memory");
       else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     } else {
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
 template <int K, int CB>
 int launch_w1(const ConvArgs& a, hipStream_t s) {
   using C = W1<K, CB>;
-  const int ntiles_px = a.M / C::TP, ctiles = a.Cout / (CB * 32);
+  const int ntiles_px = (a.M + C::TP - 1) / C::TP, ctiles = a.Cout / (CB * 32);   // (the last pixel tile may be partial)
   const int ntiles = ntiles_px * ctiles;
   static int slots = 0;
   auto k = conv1x1_wreg_kernel<K, CB>;
@@ -270,7 +277,7 @@ int launch_w1(const ConvArgs& a, hipStream_t s) {
 }  // namespace
 
 // Eligibility: 1x1 / s1, fp16 in and out, no residual / read-through / fused epilogue, dense pixel rows (the batch is one
-// flat pixel axis), K in {128, 192, 256, 384, 512}, Cout a multiple of 128, pixel count a multiple of the tile.
+// flat pixel axis), K in {128, 192, 256, 384, 512}, Cout a multiple of 128; any pixel count (a partial last pixel tile is masked).
 bool conv1x1_wreg_ok(const ConvArgs& a) {
   if (a.ksize != 1 || a.stride != 1 || a.pad != 0 || a.out_f32 || a.convt_co > 0 || a.tmode || a.phase || a.csplit || a.w2 || a.dec_preds ||
       a.res)
@@ -281,7 +288,6 @@ bool conv1x1_wreg_ok(const ConvArgs& a) {
   if (a.x_bstride != (long)a.Hi * a.Wi * a.ldx || a.y_bstride != (long)a.Ho * a.Wo * a.ldy) return false;   // flat pixel axis
   const int cb = a.Cout % 256 == 0 ? 8 : 4;
   if (cb == 4 && a.Cin > 256) return false;              // (a 128-pixel tile of K > 256 does not fit two LDS buffers)
-  if (a.M % (64 * (8 / cb))) return false;
   return (long)a.M * a.ldx * 2 < (1L << 31) && (long)a.M * a.ldy < (1L << 31);
 }
 

@@ -63,6 +63,7 @@ struct Op {
   int decode = 0;         // head output conv that also decodes its rows into the prediction tensor (no OP_DECODE launch)
   int s2c32 = 0;          // conv 3x3/s2 (32 -> 64) + 1x1 (64 -> 64) on the dedicated patch kernel (conv3x3_s2c32.hip)
   int s2c64 = 0;          // conv 3x3/s2 (64 -> 128) + 1x1 (128 -> 128) on the weights-in-registers kernel (conv3x3_s2c64.hip)
+  int headtail = 0;       // head output conv of a level that can run as conv + decode in one launch (head_tail.hip) when the raw maps are not kept
   int protor = 0;         // OP_PHASE + proto.cv3 on the weights-in-registers kernel (proto_phase_wreg.hip)
   int stemfuse = -1;      // >= 0: index of the stem op this launch also computes (conv_stem_s2c32.hip); that op is then skipped
   bool fused_away = false;
@@ -129,6 +130,8 @@ struct m355_engine {
   int sub_batch = 0, sub_ops = 0;
   // head output convs decode in their epilogue (all three levels, else none); the raw maps are then written only on request
   bool decode_fused = false;
+  int headtail_n = 0;        // head levels eligible for head_tail.hip (3: the decode launch is skipped when the raw maps are not kept)
+  int headtail_done = 0;     // ... and how many of them took it in the forward being enqueued
   int keep_raw = 1;
   // profiling: HIP events around every op launch, recorded on the caller's stream (single lane while profiling)
   bool profiling = false;
@@ -907,6 +910,12 @@ void annotate_ops(m355_engine* e) {
         if (op.decode) {
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<128x128,k1+decode>");
         }
+        if (op.kind == OP_CONV && op.out_ext == 1 && !op.decode && p.diag && p.logical.size() == 3 && p.cin == 224 && ti.C == 224 &&
+            op.in.off == 0 && p.cout == 64 + e->nc + e->nm && e->nm == 32 && e->nc <= 32 && e->convs[p.logical[0]].cin == 64 &&
+            e->convs[p.logical[1]].cin == 128 && op.raw_off == 0 && Ho * Wo >= 32 && !getenv("M355_NO_HEADTAIL")) {
+          op.headtail = 1;   // (the kernel name of the op table stays the im2col one: which path runs depends on keep_raw at forward time)
+          ++e->headtail_n;
+        }
         if (op.kind == OP_CONV && p.l3 >= 0) {   // + the 1x1 conv in the epilogue
           snprintf(op.kernel, sizeof(op.kernel), "conv_igemm<%s,k%d+1x1>", tile_names[op.tile], k);
           if (p.k == 3 && p.stride == 2 && p.cin == 32 && p.cout == 64 && p.cout2 == 64 && Ho % 8 == 0 && Wo % 16 == 0 &&
@@ -1276,6 +1285,29 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     HIP_TRY(e, hipMemcpy(p.w + (size_t)row0 * p.Kpad, rows.data(), rows.size() * sizeof(half_t),
                          hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias + row0, bias, ci.cout * sizeof(float), hipMemcpyHostToDevice));
+    if (p.diag && p.logical.size() == 3 && p.cin == 224 && p.cout == 64 + e->nc + e->nm && e->nm == 32 && e->nc <= 32 &&
+        e->convs[p.logical[0]].cin == 64 && e->convs[p.logical[1]].cin == 128) {
+      // head level (head_tail.hip): once its three convs are here, the 18 MFMA fragments of the block-diagonal matrix --
+      // box rows 0-63 over K 0-63, class rows from 64 over K 64-191 (the rows behind them are coefficient rows: zero there),
+      // coefficient rows from 64 + nc over K 192-223
+      bool all = true;
+      for (int li : p.logical) all = all && (li == idx || e->conv_loaded[li]);
+      if (all) {
+        const int rows_pad = conv_cout_pad(p.cout);
+        std::vector<half_t> full((size_t)rows_pad * p.Kpad);
+        HIP_TRY(e, hipMemcpy(full.data(), p.w, full.size() * sizeof(half_t), hipMemcpyDeviceToHost));
+        std::vector<std::pair<int, int>> fl;
+        for (int blk = 0; blk < 2; ++blk)
+          for (int sl = 0; sl < 4; ++sl) fl.push_back({32 * blk, 16 * sl});
+        for (int sl = 0; sl < 8; ++sl) fl.push_back({64, 64 + 16 * sl});
+        for (int sl = 0; sl < 2; ++sl) fl.push_back({64 + e->nc, 192 + 16 * sl});
+        if (64 + e->nc + 32 <= rows_pad) {
+          const auto fp = frag_pack(full.data(), p.Kpad, fl, false);
+          if (!p.wf) HIP_TRY(e, hipMalloc((void**)&p.wf, fp.size() * sizeof(half_t)));
+          HIP_TRY(e, hipMemcpy(p.wf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+        }
+      }
+    }
     if ((p.logical.size() == 1 || (p.l3 >= 0 && !p.composed && idx == p.logical[0])) && !p.diag && row0 == 0) {   // fragment-ordered copies for the weights-in-registers kernels
       const auto fl = frag_list(ci.k, ci.cin, ci.cout);
       if (!fl.empty()) {
@@ -1302,6 +1334,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
     if (!e->conv_loaded[i]) return e->fail(M355_ERR_STATE, std::string("weights not set for ") + e->convs[i].name);
   hipStream_t s_main = (hipStream_t)stream;
   const int rw = 64 + e->nc + e->nm;
+  e->headtail_done = 0;
   const bool lanes = e->nlanes > 1 && !e->profiling;   // per-op event timing needs one stream
   // ops [lo, hi) over images [b0, b0 + Bq)
   auto run_range = [&](size_t lo, size_t hi, const int b0, const int Bq) -> int {
@@ -1409,6 +1442,18 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           const PhysConv& pf = e->phys[op.conv];
           a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2; a.wf2 = pf.wf2;
         }
+        if (op.headtail && !e->keep_raw && e->headtail_n == 3 && p.wf && !b0) {   // conv + decode of this level in one launch
+          HeadTailArgs ha{};
+          ha.x = ti.p; ha.ldx = ti.C; ha.M = (long)Bq * ti.H * ti.W; ha.HW = ti.H * ti.W; ha.W = ti.W;
+          ha.stride = (float)(e->desc.in_h / ti.H);
+          ha.A = e->A; ha.level_off = op.level_off; ha.nc = e->nc; ha.nm = e->nm;
+          ha.wf = p.wf; ha.bias = p.bias; ha.preds = d_preds;
+          if (head_tail_ok(ha)) {
+            rc = launch_head_tail(ha, s);
+            ++e->headtail_done;
+            break;
+          }
+        }
         a.tileq = knobs().static_tiles ? nullptr : e->tileq + 4 * oi;
         if (op.stemfuse >= 0) {
           const Op& so = e->ops[op.stemfuse];
@@ -1475,6 +1520,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
       }
       case OP_DECODE:
         if (e->decode_fused) break;   // the three head output convs wrote the prediction rows
+        if (e->headtail_done == 3) break;   // so did the three head_tail launches of this forward
         rc = launch_head_decode(e->raw, Bq, e->desc.in_h, e->desc.in_w, e->nc, e->nm, d_preds, s);
         break;
     }
@@ -1518,6 +1564,18 @@ int m355_get_op_info(const m355_engine* e, int idx, m355_op_info* out) {
   snprintf(out->layer, sizeof(out->layer), "%s", op.layer);
   out->flops_per_image = op.flops;
   out->bytes_per_image = op.bytes;
+  if (e->headtail_n == 3 && !e->keep_raw) {   // the head levels run as conv + decode launches (head_tail.hip), no decode launch
+    const int wo = 4 + e->nc + e->nm;
+    if (op.headtail) {
+      const Tensor& ti = e->tensors[op.in.t];
+      snprintf(out->kernel, sizeof(out->kernel), "head_tail<128px>");
+      snprintf(out->layer, sizeof(out->layer), "%s+decode", op.layer);
+      out->bytes_per_image = (double)ti.H * ti.W * (ti.C * 2 + wo * 4);
+    } else if (op.kind == OP_DECODE) {
+      snprintf(out->kernel, sizeof(out->kernel), "(none)");
+      out->bytes_per_image = 0;
+    }
+  }
   out->weight_bytes = op.wbytes;
   return M355_OK;
 }
@@ -1563,7 +1621,7 @@ int m355_set_keep_raw(m355_engine* e, int keep) {
 
 int m355_copy_raw_head(m355_engine* e, int B, float* d_out, void* stream) {
   if (!e) return M355_ERR_INVALID;
-  if (e->decode_fused && !e->keep_raw)
+  if ((e->decode_fused || e->headtail_n == 3) && !e->keep_raw)
     return e->fail(M355_ERR_STATE, "the raw head maps are not written (m355_set_keep_raw(e, 1) before the forward)");
   if (!d_out || B < 1 || B > e->desc.max_batch) return e->fail(M355_ERR_INVALID, "bad argument");
   const size_t n = (size_t)B * e->A * (64 + e->nc + e->nm) * sizeof(float);

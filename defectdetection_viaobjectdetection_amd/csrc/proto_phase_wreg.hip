@@ -21,6 +21,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <hip/hip_runtime.h>
+
 #include "common.h"
 
 namespace m355 {
@@ -31,7 +33,7 @@ typedef float float16v __attribute__((ext_vector_type(16)));
 constexpr int TH = 8, TW = 16, PP = 17, ROWB = 256, NWAVES = 8;
 constexpr int PROWS = (TH + 1) * PP;                 // 153 patch pixels
 constexpr int NPIECES = (PROWS + 3) / 4;             // 39 DMA pieces of 4 rows
-constexpr int P_IT = (NPIECES + NWAVES - 1) / NWAVES;   // 5
+constexpr int G_SPLIT = 27, P_IT = 7;                // DMA pieces of waves 0-3 / per wave (issue_patch)
 constexpr int PATCH_BYTES = NPIECES * 1024;          // 39936
 constexpr int NBUF = 2;
 constexpr int Z_OFF = NBUF * PATCH_BYTES;            // 128 pixels x 256 bytes: SiLU(phase conv) as fp16
@@ -109,16 +111,19 @@ __global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs
     int r0;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(r0));
     const int lsl = r0 & 15;
-    r0 = 4 * wave + (r0 >> 4);
+    // Waves 0-3 (whose next stop is barrier A, where they wait for the other team's K loop) take 27 of the 39 pieces, waves
+    // 4-7 (which go straight into their K loop: the critical path of the tile) the other 12.  Wave w of a team: g = g0 + w + 4 i.
+    const int g0 = wave < 4 ? 0 : G_SPLIT, g1 = wave < 4 ? G_SPLIT : NPIECES;
+    r0 = 4 * (g0 + m) + (r0 >> 4);
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
-      const int g = wave + NWAVES * i;
-      if (g < NPIECES) {
-        const int R = r0 + 4 * NWAVES * i;
-        const int pr = (R * 3856) >> 16, pc = R - pr * PP;          // R / 17, R % 17 (exact for R < 200)
+      const int g = g0 + m + 4 * i;
+      if (g < g1) {
+        const int R = r0 + 16 * i;
+        const int pr = __umul24(R, 3856) >> 16, pc = R - pr * PP;  // R / 17, R % 17 (exact for R < 200)
         const int yy = oy + pr, xx = ox + pc;
         const bool ok = R < PROWS && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const int rel = ((pr * W + pc) * a.ldx + (((lsl ^ pc) & 15) << 3)) * 2;
+        const int rel = (__mul24(__mul24(pr, W) + pc, a.ldx) + (((lsl ^ pc) & 15) << 3)) * 2;
         dma16(rs_x, ok ? origin + rel : (int)0x80000000, tb * img_stride, smem + buf * PATCH_BYTES + g * 1024);   // out of range = zeros
       }
     }

@@ -307,7 +307,21 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
     import os
     from defectdetection_viaobjectdetection_amd.engine import SegEngine
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
-    os.environ["M355_NO_S2C32"] = "1"       # the 32 -> 64 pair has its own patch kernel by default (next test); this one is about the epilogue fusion
+    # the 32 -> 64 pair has its own patch kernel by default (next test) and the separate 128 -> 128 cv1 would run on the
+    # weights-in-registers 1x1 kernel (another summation order): this test is about the im2col kernel's epilogue fusion
+    knobs = {"M355_NO_S2C32": "1", "M355_NO_W1": "1", "M355_NO_S2C64": "1"}
+    os.environ.update(knobs)
+    try:
+        _cv1_fusion_cases(cuda_device)
+    finally:
+        for k in knobs:
+            os.environ.pop(k, None)
+
+
+def _cv1_fusion_cases(cuda_device):
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
     for scale, nfused in (("s", 2), ("n", 1)):
         sd = synthetic_state_dict(scale, 1, seed=0)
         # 7 images of 608 x 640: the 76 x 80 map of model.3 gives 332.5 pixel tiles (a partial one), enough for the 128-channel tile
@@ -331,7 +345,6 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
         if saved is not None:
             os.environ["M355_NO_CVFUSE"] = saved
         assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), scale
-    os.environ.pop("M355_NO_S2C32", None)
 
 
 def test_s2c32_patch_kernel_matches_the_im2col_form(cuda_device):
@@ -428,6 +441,41 @@ def test_decode_in_the_head_epilogue_is_bit_identical(cuda_device):
     assert torch.equal(outs["fused"][0], outs["separate"][0]) and torch.equal(outs["fused_keep_raw"][0], outs["separate"][0])
     assert torch.equal(outs["fused"][1], outs["separate"][1])
     assert torch.equal(outs["fused_keep_raw"][2], outs["separate"][2])
+
+
+@pytest.mark.parametrize("shape,batch", [((608, 640), 7), ((640, 640), 3), ((320, 320), 5)])
+def test_head_levels_as_conv_plus_decode_launches(cuda_device, shape, batch):
+    """Predict path (raw head maps not kept): each head level's three output convs and the decode of its rows run as ONE
+    launch (head_tail.hip) and head_decode_kernel is not launched; with the raw maps kept, the im2col launch per level + the
+    decode launch.  Same arithmetic after the dot products (the decode is restated operation for operation); the dot products
+    themselves sum in another order (32x32x16 vs 16x16x32 MFMA), so the rows agree to fp32 rounding, not bit for bit.
+    Shapes: 608 x 640 (76 x 80 map: fast row stores; 38 x 40 and 19 x 20: pixel blocks that cross image boundaries), three
+    images of 640 x 640 (a partial last tile on the 40 x 40 level), 320 x 320 (10 x 10 = 100 anchors per image)."""
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(batch, seed=52)[:, :shape[0], :shape[1]].copy()).to(cuda_device)
+    outs = {}
+    for keep in (False, True):
+        eng = SegEngine("s", 1, shape, max_batch=batch, keep_raw=keep)
+        kinds = [o["kernel"] for o in eng.op_infos()]
+        assert sum(k.startswith("head_tail") for k in kinds) == (0 if keep else 3)
+        eng.load_state_dict(sd)
+        p, q = eng.forward(imgs)
+        torch.cuda.synchronize()
+        outs[keep] = (p.clone(), q.clone())
+        if not keep:
+            with pytest.raises(RuntimeError):
+                eng.raw_head(batch)
+        eng.close()
+    a, b = outs[False][0], outs[True][0]
+    assert a.shape == b.shape and torch.isfinite(a).all()
+    assert torch.equal(outs[False][1], outs[True][1])                       # prototypes: untouched
+    d = (a - b).abs()
+    print(f"{shape} b{batch}: box max {float(d[..., :4].max()):.2e} px, score max {float(d[..., 4].max()):.2e}, "
+          f"coef max {float(d[..., 5:].max()):.2e}")
+    assert float(d[..., :4].max()) <= 2e-2 and float(d[..., 4].max()) <= 1e-5
+    assert float((d[..., 5:] / (1.0 + b[..., 5:].abs())).max()) <= 1e-4
 
 
 def test_stem_fused_into_the_patch_kernel_matches_the_two_launches(cuda_device):

@@ -95,6 +95,9 @@ CONV_CASES = [
     (4, 20, 20, 512, 512, 1, 1, 1, False, 32),      # two channel tiles of 256: blocks cross the channel-tile boundary
     (24, 40, 40, 512, 256, 1, 1, 1, False, 32),     # 600 tiles over 256 blocks: 2 or 3 tiles per block, K = 512
     (2, 8, 8, 128, 128, 1, 1, 1, False, 32),        # one 128-pixel tile, K = 128
+    (3, 40, 40, 256, 128, 1, 1, 1, False, 32),      # 4800 pixels = 37.5 tiles of 128: the partial last pixel tile is masked
+    (3, 20, 20, 512, 512, 1, 1, 1, False, 32),      # 1200 pixels = 18.75 tiles of 64, two channel tiles: a partial tile mid-walk
+    (1, 10, 10, 384, 256, 1, 1, 1, False, 32),      # 100 pixels: two tiles, two buffers
     # slab kernel for narrow maps (25): R full-width rows x 64 channels, linear pixel groups
     (2, 20, 20, 256, 256, 3, 1, 1, True, 25),       # the 20x20 C2f layers: two slabs of 10 rows, 12.5 groups
     (3, 20, 20, 512, 224, 3, 1, 0, False, 25),      # fused head-level convs: ragged channel tile (224 = 3 x 64 + 32)

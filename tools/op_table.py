@@ -14,7 +14,7 @@ scale = sys.argv[1] if len(sys.argv) > 1 else "s"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 S = int(sys.argv[3]) if len(sys.argv) > 3 else 640
 steps = int(sys.argv[4]) if len(sys.argv) > 4 else 10
-eng = SegEngine(scale, 1, (S, S), max_batch=B)
+eng = SegEngine(scale, 1, (S, S), max_batch=B, keep_raw=False)   # the predict path
 eng.load_state_dict(synthetic_state_dict(scale, 1, seed=0))
 x = torch.from_numpy(np.random.default_rng(0).integers(0, 255, (B, S, S, 3), dtype=np.uint8)).cuda()
 for _ in range(3):
