@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="one engine, one stream lane inside it (M355_NO_LANES), whole-batch launches (M355_NO_SUBBATCH): every kernel runs alone, so rocprofv3's "
                          "per-kernel averages and the live event samples describe the same launches")
-    ap.add_argument("--profile-every", type=int, default=50,
+    ap.add_argument("--profile-every", type=int, default=100,
                     help="record per-op HIP events on every n-th timed step (an event pair per launch costs "
                          "~8 us of serialisation, ~0.6 ms per fully instrumented step)")
     args = ap.parse_args()
