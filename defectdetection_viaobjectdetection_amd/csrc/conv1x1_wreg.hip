@@ -63,6 +63,10 @@ struct W1 {
   static constexpr int P_IT = NPIECES / NWAVES;
   static constexpr int NBUF = (3 * TILE_BYTES <= 120 * 1024) ? 3 : 2;
   static constexpr int SWM = (K % 128 == 0) ? 15 : 7;  // XOR mask on the chunk index
+  // XOR key of a pixel row: 256-byte multiples (K % 128 == 0) start every row on bank 0 -> pixel & 15; 384-byte rows (K = 192)
+  // alternate between two bank halves -> (pixel >> 1) & 7 (pixel & 7 left a 2-way conflict: 9 % of the K = 192 launch by
+  // SQ_LDS_BANK_CONFLICT, profiles/r03_pmc_mfma.json before the fix)
+  static constexpr int SWS = (K % 128 == 0) ? 0 : 1;
   static constexpr int STG_OFF = NBUF * TILE_BYTES;    // 8 waves x 32 pixels x 64 bytes (one pixel block at a time)
   static constexpr int BIAS_OFF = STG_OFF + NWAVES * 2048;
   static constexpr int LDS_BYTES = BIAS_OFF + 1024;
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
     for (int i = 0; i < C::P_IT; ++i) {
       const int cid = 64 * (wave + NWAVES * i) + ln;
       const int px = cid / C::NCH, slot = cid - px * C::NCH;
-      const int cc = slot ^ (px & C::SWM);
+      const int cc = slot ^ ((px >> C::SWS) & C::SWM);
       dma16(rs_x, px < npx ? (px * a.ldx + cc * 8) * 2 : (int)0x80000000, soff,
             smem + buf * C::TILE_BYTES + (wave + NWAVES * i) * 1024);   // past the tensor: zeros
     }
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
   for (int pb = 0; pb < 2; ++pb) {
     const int px = 64 * ph + 32 * pb + n;
     offp[pb] = px * C::RB;
-    swz[pb] = px & C::SWM;
+    swz[pb] = (px >> C::SWS) & C::SWM;
   }
   // output staging: this wave's 64 pixels x 32 channels (64-byte rows); chunk XOR (pixel >> 1) & 3
   char* const stg = smem + C::STG_OFF + wave * 2048;

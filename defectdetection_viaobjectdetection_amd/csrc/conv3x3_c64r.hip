@@ -8,15 +8,24 @@
 // tile re-streamed the 72 KB weight matrix through LDS-DMA (72 pieces of 1 KiB at 60-180 issue cycles each) and read it
 // back fragment by fragment, one ds_read per MFMA on top of the activation fragment.  A 64 x 576 weight matrix is 36
 // fragments of a 32-row block: 144 VGPRs.  Here every wave keeps the fragments of ITS channel block in registers for the
-// whole life of a persistent block (c2f_c32.hip showed the form): no weight traffic through LDS at all, one ds_read_b128
-// per MFMA (the activation fragment), three DMA pieces per wave and tile (the 10 x 18-pixel patch, 23 KB).
+// whole life of a persistent block: no weight traffic through LDS at all, one ds_read_b128 per MFMA (the activation
+// fragment), the 10 x 18-pixel patch (23 KB) by LDS-DMA.
 //
 // Block = 8 waves (two per SIMD), one block per CU, wave (m = wave & 1, q = wave >> 1) = 32 channels x tile rows 2q, 2q+1.
-// Per tile: the patch of tile i + 2 is issued, the 36 K slices of tile i run in tap order with the fragments of tap t + 1
-// read under the MFMAs of tap t, SiLU (+ residual, read in the accumulator layout at the top of the tile), fp16, and the
-// wave's 32 pixels x 32 channels leave through 2 KB of LDS as 64-byte row segments.  One barrier per tile.
+// First form (round 3, 27.5 us -- no better than the halo kernel): all eight waves in lockstep, one barrier per tile; the stamps
+// showed 5.1 k cycles per tile for 2.3 k cycles of MFMA: the two waves of a SIMD were in the K loop together (half the pipe
+// each), then in the SiLUs together, then in the stores.  This form (the schedule of conv3x3_s2c64.hip): TEAM t = wave >> 2
+// owns tile rows 4t .. 4t+3 and the teams run half a tile apart,
+//   slot 1   team 0: K(i)                           team 1: epilogue(i - 1), + part of the patch of tile i + 1
+//   slot 2   team 0: epilogue(i), + rest of patch   team 1: K(i)
+// one barrier after each slot, so the MFMA pipe of a SIMD serves one wave at a time and the other wave's SiLU / stores run
+// beside it.  Epilogue: SiLU (+ residual, loaded in the accumulator layout BEFORE the DMA issue so that the wait for it does
+// not wait for the pieces behind it), fp16, 2 KB of LDS per wave, 64-byte row segments out.  The DMA is issued
+// unconditionally (a tile that does not exist is all out-of-range offsets: zeros into the idle buffer) so that every wait
+// count is static.
 // LDS image (as conv3x3_m32.hip): one 128-byte row per patch pixel, pitch 18, the 16-byte chunk index XOR-ed with
 // (patch column >> 1) & 7 on the DMA source side and on the reads: conflict free for all nine tap shifts.
+#include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -31,12 +40,11 @@ constexpr int TH = 8, TW = 16, PP = 18, ROWB = 128;
 constexpr int PROWS = (TH + 2) * PP;                 // 180 patch pixels
 constexpr int NPIECES = (PROWS + 7) / 8;             // 23 DMA pieces of 8 rows
 constexpr int PATCH_BYTES = NPIECES * 1024;          // 23552
-constexpr int NBUF = 3;                              // tile i (compute), i + 1 (landed / landing), i + 2 (being issued)
 constexpr int NWAVES = 8;
-constexpr int P_IT = (NPIECES + NWAVES - 1) / NWAVES;   // 3
-constexpr int STG_OFF = NBUF * PATCH_BYTES;          // output staging: 8 waves x 32 pixels x 64 bytes
+constexpr int G_SPLIT = 11, P_IT = 3;                // pieces 0-10: team 1 (slot 1), 11-22: team 0 (slot 2); per wave
+constexpr int STG_OFF = 2 * PATCH_BYTES;             // output staging: 8 waves x 32 pixels x 64 bytes
 constexpr int BIAS_OFF = STG_OFF + NWAVES * 2048;
-constexpr int LDS_BYTES = BIAS_OFF + 256;            // 87296
+constexpr int LDS_BYTES = BIAS_OFF + 256;            // 63744
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
@@ -61,6 +69,12 @@ __device__ __forceinline__ void silu16(float16v& v) {
   for (int j = 0; j < 16; ++j) v[j] = v[j] * t[j];
 }
 
+__device__ __forceinline__ int lane_id() {            // volatile: lane-derived values are rebuilt where they are used, not kept
+  int ln;                                             // live (= spilled) across the K loop; a scratch reload waits on vmcnt(0)
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+  return ln;
+}
+
 __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ntiles, int sx, int sy,
                                                              int sb) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -68,7 +82,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = a.Hi, W = a.Wi, nwg = gridDim.x;
   const int n = lane & 31, h = lane >> 5;
-  const int m = wave & 1, q = wave >> 1;
+  const int m = wave & 1, q = wave >> 1, team = wave >> 2;
 
   if (tid < 64) ((float*)(smem + BIAS_OFF))[tid] = a.bias[tid];
 
@@ -84,10 +98,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
     for (int s = 0; s < 36; ++s) wv[s] = *(const half8*)(wp + 16 * s);
   }
 
-  // ---- tile walk (static, XCD-aware; stepped with carries: no division in the loop -- c2f_c32.hip)
+  // ---- tile walk (static, XCD-aware; decoded once, then stepped with carries)
   auto decode = [&](int vb, int& tb, int& ty, int& tx) __attribute__((always_inline)) {
     const int xcd = vb & 7, qq = ntiles >> 3, r = ntiles & 7;
-    const int L = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (vb >> 3);
+    const int L = (nwg & 7) ? vb : (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + (vb >> 3);
     tx = L % tiles_x;
     const int rest = L / tiles_x;
     tb = rest / tiles_y;
@@ -105,70 +119,38 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
       (void*)a.x, 0, (int)((nimg - 1) * a.x_bstride + (long)H * W * a.ldx) * 2, 0x00020000);
   const int img_stride = (int)a.x_bstride * 2;
 
-  // ---- patch pieces: wave w owns pieces g = w + 8 i (8 LDS rows each); lane = (row 8 g + lane / 8, chunk slot lane % 8)
-  int prel[P_IT], prc[P_IT];
-#pragma unroll
-  for (int i = 0; i < P_IT; ++i) {
-    const int R = 8 * (wave + NWAVES * i) + (lane >> 3);
-    const int pr = R / PP, pc = R - pr * PP;
-    const int cc = (lane & 7) ^ ((pc >> 1) & 7);
-    prel[i] = ((pr * W + pc) * a.ldx + cc * 8) * 2;
-    prc[i] = (R < PROWS ? pr : 255) | (pc << 8);              // rows past the patch: never valid
-  }
-  auto issue_patch = [&](int tb, int y0, int x0, int buf) __attribute__((always_inline)) {
-    const int origin = (((y0 - 1) * W + (x0 - 1)) * a.ldx) * 2;   // may be negative for border tiles: those lanes are masked
-    const bool interior = y0 >= 1 && y0 + TH + 1 <= H && x0 >= 1 && x0 + TW + 1 <= W;
+  // ---- patch pieces (8 LDS rows each): wave w of a team owns pieces g = g0 + (w & 3) + 4 i; lane = (row 8 g + lane / 8, chunk
+  // slot lane % 8).  `valid` false: every lane out of range (zeros into the idle buffer), same instruction count.
+  auto issue_patch = [&](bool valid, int tb, int y0, int x0, int buf, int g0, int g1) __attribute__((always_inline)) {
+    const int ln = lane_id();
+    const int r0 = 8 * (g0 + (wave & 3)) + (ln >> 3), slot = ln & 7;
+    const int origin = (__mul24(y0 - 1, W) + x0 - 1) * a.ldx * 2;     // may be negative for border tiles: those lanes are masked
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
-      const int g = wave + NWAVES * i;
-      if (g < NPIECES) {
-        const int yy = y0 - 1 + (prc[i] & 255), xx = x0 - 1 + (prc[i] >> 8);
-        const bool ok = (prc[i] & 255) != 255 && (interior || ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W));
-        dma16(rs_x, ok ? origin + prel[i] : (int)0x80000000, tb * img_stride, smem + buf * PATCH_BYTES + g * 1024);
+      const int g = g0 + (wave & 3) + 4 * i;
+      if (g < g1) {
+        const int R = r0 + 32 * i;
+        const int pr = __umul24(R, 3641) >> 16, pc = R - pr * PP;     // R / 18, R % 18 (exact for R < 200)
+        const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
+        const bool ok = valid && R < PROWS && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
+        const int rel = (__mul24(__mul24(pr, W) + pc, a.ldx) + ((slot ^ ((pc >> 1) & 7)) << 3)) * 2;
+        dma16(rs_x, ok ? origin + rel : (int)0x80000000, tb * img_stride, smem + buf * PATCH_BYTES + g * 1024);
       }
     }
   };
 
   // ---- fragment offsets (tile independent): pixel (2 q + (n >> 4), n & 15) of the tile, tap column shift kw, K slice s
-  const int r = 2 * q + (n >> 4), c = n & 15;
   int offb[3][4];
+  {
+    const int r = 2 * q + (n >> 4), c = n & 15;
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) {
-    const int col = c + kw;
+    for (int kw = 0; kw < 3; ++kw) {
+      const int col = c + kw;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) offb[kw][s] = (r * PP + col) * ROWB + (((2 * s + h) ^ ((col >> 1) & 7)) << 4);
-  }
-  // output staging (this wave's 32 pixels x 32 channels = 64-byte rows): write chunk (2 h, 2 h + 1) of pixel n, read back
-  // pixel 16 i + lane / 4, chunk lane % 4; chunk index XOR (pixel >> 1) & 3
-  char* const stg = smem + STG_OFF + wave * 2048;
-  const int st_w0 = n * 64 + (((2 * h) ^ ((n >> 1) & 3)) << 4), st_w1 = n * 64 + (((2 * h + 1) ^ ((n >> 1) & 3)) << 4);
-  const int st_p = lane >> 2, st_k = lane & 3;
-
-  // Iteration `it`: issue the patch of tile it + 2, compute tile it.  Slot k of the arrays = tile it + k.
-  int tbi[3], ty0[3], tx0[3];
-  bool have[3];
-  int nb_, nty, ntx;
-  int vbn = blockIdx.x + nwg;
-  decode(blockIdx.x, nb_, nty, ntx);
-  have[0] = true;
-  tbi[0] = nb_; ty0[0] = nty * TH; tx0[0] = ntx * TW;
-  auto plan = [&](int k) __attribute__((always_inline)) {
-    have[k] = have[k - 1] && vbn < ntiles;
-    if (have[k]) {
-      step_tile(nb_, nty, ntx);
-      tbi[k] = nb_; ty0[k] = nty * TH; tx0[k] = ntx * TW;
-      vbn += nwg;
+      for (int s = 0; s < 4; ++s) offb[kw][s] = (r * PP + col) * ROWB + (((2 * s + h) ^ ((col >> 1) & 7)) << 4);
     }
-  };
-  plan(1);
-  issue_patch(tbi[0], ty0[0], tx0[0], 0);
-  if (have[1]) issue_patch(tbi[1], ty0[1], tx0[1], 1);
-  // vmcnt(0) lgkmcnt(0) as the BUILTIN: the compiler's wait-count pass sees it and knows the 36 weight loads are done.
-  // With an inline-asm wait it re-waited for them inside the tile loop -- vmcnt(35) ... vmcnt(0) in front of the MFMAs of
-  // EVERY tile -- and the vmcnt(0) there drained the patch prefetch and the previous tile's stores: 9.7 k cycles per tile
-  // instead of 2.5 k (first version of this kernel: 32 us per layer).
-  __builtin_amdgcn_s_waitcnt(0x0070);
-  __builtin_amdgcn_s_barrier();                            // patches 0 and 1 landed, biases visible
+  }
+  char* const stg = smem + STG_OFF + wave * 2048;
 
   // diagnostic launches only (a.stamps, M355_STAMPS through m355_conv2d_fwd): cycles per section and wave
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = a.stamps ? __builtin_amdgcn_s_memtime() : 0;
@@ -182,20 +164,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
     tacc[k] += tn - tlast;                                                                                \
     tlast = tn;                                                                                           \
   }
-  for (int it = 0;; ++it) {
-    plan(2);
-    ++ntile;
-    const char* const pb = smem + (it % NBUF) * PATCH_BYTES;
-    if (have[2]) issue_patch(tbi[2], ty0[2], tx0[2], (it + 2) % NBUF);
-    C64_STAMP(0)   // tile step + DMA issue
-    // ---- K loop: 9 taps x 4 slices; the fragments of tap t + 1 are read under the MFMAs of tap t
-    float16v acc;
-    {
+
+  float16v acc;
+  // K: 9 taps x 4 slices out of patch buffer pb; the fragments of tap t + 1 are read under the MFMAs of tap t
+  auto k_loop = [&](const char* pb) __attribute__((always_inline)) {
 #pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        const float4v u = *(const float4v*)(smem + BIAS_OFF + (32 * m + 16 * h + 4 * qd) * 4);
-        acc[qd * 4 + 0] = u[0]; acc[qd * 4 + 1] = u[1]; acc[qd * 4 + 2] = u[2]; acc[qd * 4 + 3] = u[3];
-      }
+    for (int qd = 0; qd < 4; ++qd) {
+      const float4v u = *(const float4v*)(smem + BIAS_OFF + (32 * m + 16 * h + 4 * qd) * 4);
+      acc[qd * 4 + 0] = u[0]; acc[qd * 4 + 1] = u[1]; acc[qd * 4 + 2] = u[2]; acc[qd * 4 + 3] = u[3];
     }
     half8 fr[2][4];
 #pragma unroll
@@ -211,18 +187,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[4 * tap + s], fr[tap & 1][s], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
-    C64_STAMP(1)   // reads + MFMAs
-    // ---- epilogue: SiLU, + residual, fp16 (the rounding order of the other conv kernels), transpose through LDS, store.
-    // The residual (accumulator layout, two 16-byte loads per lane) is loaded HERE, under the SiLUs: the compiler waits for
-    // it with vmcnt(0) (the conditional patch issue hides the count from it), which at the top of the tile drained the
-    // patch prefetch; by now the pieces issued before the K loop have landed anyway.
+  };
+  // epilogue of tile (tb, y0, x0) + the issue of this team's part of the next patch between the residual loads and their use
+  auto epilogue = [&](int tb, int y0, int x0, bool nvalid, int ntb, int ny0, int nx0, int nbuf, int g0, int g1) __attribute__((always_inline)) {
+    const int ln = lane_id();
+    const int en = ln & 31, eh = ln >> 5, st_p = ln >> 2, st_k = ln & 3;
     half8 res0 = (half8)(half_t)0.f, res1 = res0;
     if (a.res) {
-      const long pix = (long)(ty0[0] + r) * W + tx0[0] + c;
-      const half_t* rp = a.res + (long)tbi[0] * a.r_bstride + pix * a.ldr + 32 * m + 16 * h;
+      const long pix = (long)(y0 + 2 * q + (en >> 4)) * W + x0 + (en & 15);
+      const half_t* rp = a.res + (long)tb * a.r_bstride + pix * a.ldr + 32 * m + 16 * eh;
       res0 = *(const half8*)rp;
       res1 = *(const half8*)(rp + 8);
     }
+    issue_patch(nvalid, ntb, ny0, nx0, nbuf, g0, g1);
     if (a.act) silu16(acc);
     half8 o0, o1;
     {
@@ -235,35 +212,70 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64r_kernel(const ConvArgs a, 
         o1[j] = m355_to_half(v1);
       }
     }
-    C64_STAMP(2)   // residual wait + SiLU + convert
-    *(half8*)(stg + st_w0) = o0;
-    *(half8*)(stg + st_w1) = o1;
+    *(half8*)(stg + en * 64 + (((2 * eh) ^ ((en >> 1) & 3)) << 4)) = o0;
+    *(half8*)(stg + en * 64 + (((2 * eh + 1) ^ ((en >> 1) & 3)) << 4)) = o1;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-      half_t* const yb = (half_t*)a.y + (long)tbi[0] * a.y_bstride + ((long)(ty0[0] + 2 * q) * W + tx0[0]) * a.ldy + 32 * m;
+    half_t* const yb = (half_t*)a.y + (long)tb * a.y_bstride + ((long)(y0 + 2 * q) * W + x0) * a.ldy + 32 * m;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {      // pixels 16 i .. 16 i + 15 of the block = tile row 2 q + i
-        const int p = 16 * i + st_p;
-        const half8 v = *(const half8*)(stg + p * 64 + ((st_k ^ ((p >> 1) & 3)) << 4));
-        *(half8*)(yb + ((long)i * W + st_p) * a.ldy + st_k * 8) = v;
-      }
+    for (int i = 0; i < 2; ++i) {      // pixels 16 i .. 16 i + 15 of the block = tile row 2 q + i
+      const int p = 16 * i + st_p;
+      const half8 v = *(const half8*)(stg + p * 64 + ((st_k ^ ((p >> 1) & 3)) << 4));
+      *(half8*)(yb + ((long)i * W + st_p) * a.ldy + st_k * 8) = v;
     }
-    // the patch of tile it + 1 (issued one iteration ago, or in the prologue) has landed for this wave: everything older than
-    // this iteration's own patch pieces and stores (the residual loads were consumed above)
-    C64_STAMP(3)   // staging + stores
-    if (have[2]) {
-      if (wave + 2 * NWAVES < NPIECES) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");   // 3 pieces + 2 stores
-      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");                                // 2 pieces + 2 stores
+  };
+
+  int vb = blockIdx.x, wb, wy, wx;
+  decode(vb, wb, wy, wx);
+  int tb = wb, y0 = wy * TH, x0 = wx * TW, ptb = 0, py0 = 0, px0 = 0;
+  if (team == 1) issue_patch(true, tb, y0, x0, 0, 0, G_SPLIT);
+  else issue_patch(true, tb, y0, x0, 0, G_SPLIT, NPIECES);
+  // vmcnt(0) lgkmcnt(0) as the BUILTIN: the compiler's wait-count pass sees it and knows the 36 weight loads are done (with an
+  // inline-asm wait it re-waited for them inside the tile loop and drained the patch prefetch and the stores: 9.7 k cycles per tile)
+  __builtin_amdgcn_s_waitcnt(0x0070);
+  __builtin_amdgcn_s_barrier();
+
+  for (int it = 0;; ++it) {
+    ++ntile;
+    const bool more = vb + nwg < ntiles;
+    int ntb = tb, ny0 = y0, nx0 = x0;
+    if (more) {
+      step_tile(wb, wy, wx);
+      ntb = wb; ny0 = wy * TH; nx0 = wx * TW;
+    }
+    C64_STAMP(0)   // tile step
+    // ---- slot 1
+    if (team == 0) {
+      k_loop(smem + (it & 1) * PATCH_BYTES);
+      C64_STAMP(1)   // K
     } else {
-      asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+      if (it > 0) epilogue(ptb, py0, px0, more, ntb, ny0, nx0, (it + 1) & 1, 0, G_SPLIT);
+      else issue_patch(more, ntb, ny0, nx0, (it + 1) & 1, 0, G_SPLIT);
+      C64_STAMP(2)   // epilogue + DMA issue
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    C64_STAMP(3)   // barrier 1
+    // ---- slot 2
+    if (team == 0) {
+      epilogue(tb, y0, x0, more, ntb, ny0, nx0, (it + 1) & 1, G_SPLIT, NPIECES);
+      C64_STAMP(2)
+    } else {
+      k_loop(smem + (it & 1) * PATCH_BYTES);
+      C64_STAMP(1)
+    }
+    // the next patch has landed for this wave: its pieces are older than the two stores of this tile's epilogue (team 1 in
+    // its first tile has no stores yet)
+    if (team == 1 && it == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
     C64_STAMP(4)   // next patch landed
     __builtin_amdgcn_s_barrier();
-    C64_STAMP(5)   // barrier
-    if (!have[1]) break;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) { tbi[k] = tbi[k + 1]; ty0[k] = ty0[k + 1]; tx0[k] = tx0[k + 1]; have[k] = have[k + 1]; }
+    C64_STAMP(5)   // barrier 2
+    ptb = tb; py0 = y0; px0 = x0;
+    if (!more) break;
+    vb += nwg;
+    tb = ntb; y0 = ny0; x0 = nx0;
   }
+  if (team == 1) epilogue(ptb, py0, px0, false, ptb, py0, px0, 0, 0, 0);   // the last tile of team 1 (no further patch: g0 = g1)
   if (a.stamps && lane == 0) {
     unsigned long long* o = a.stamps + ((long)blockIdx.x * NWAVES + wave) * 8;
     for (int k = 0; k < 6; ++k) o[k] = tacc[k];
