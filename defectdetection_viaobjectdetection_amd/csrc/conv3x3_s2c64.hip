@@ -70,7 +70,7 @@ __device__ __forceinline__ int lane_id() {            // volatile: lane-derived 
 }
 
 __global__ __launch_bounds__(512, 2) void conv3x3_s2c64_cv1_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ntiles, int sx,
-                                                                  int sy, int sb, unsigned long long* stamps) {
+                                                                  int sy, int sb, int prio, unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -172,6 +172,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2c64_cv1_kernel(const ConvArg
         acc[qd * 4 + 0] = u[0]; acc[qd * 4 + 1] = u[1]; acc[qd * 4 + 2] = u[2]; acc[qd * 4 + 3] = u[3];
       }
     }
+    if (prio) __builtin_amdgcn_s_setprio(1);          // (the K loop is the slot's critical path; the partner is in SiLU / stores)
     half8 fr[2][4];
     auto read_tap = [&](int tap, int b) __attribute__((always_inline)) {
       const int kh = tap / 3, kw = tap - 3 * kh;
@@ -189,6 +190,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_s2c64_cv1_kernel(const ConvArg
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[4 * tap + s], fr[tap & 1][s], acc, 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
   };
   // Z: SiLU, fp16, into the team's Z image [pixel n][128 channels], chunk XOR (pixel & 15)
   auto z_write = [&]() __attribute__((always_inline)) {
@@ -358,6 +360,7 @@ int launch_conv_s2c64_cv1(const ConvArgs& a, hipStream_t s) {
   const int grid = ntiles <= slots ? ntiles : slots;
   const int step = grid >> 3;                          // tiles between two visits of a block (it walks only when grid = slots, % 8 == 0)
   const int sx = step % tiles_x, sy = (step / tiles_x) % tiles_y, sb = step / tiles_x / tiles_y;
+  static const int prio = getenv("M355_S2C64_PRIO") ? atoi(getenv("M355_S2C64_PRIO")) : 0;   // experiment: s_setprio(1) around the K loop
   // diagnostic: M355_S2C64_STAMPS=<file> -> per-wave section cycles of the LAST launch, written after a stream sync [sync]
   static const char* st_path = getenv("M355_S2C64_STAMPS");
   static unsigned long long* d_st = nullptr;
@@ -365,7 +368,7 @@ int launch_conv_s2c64_cv1(const ConvArgs& a, hipStream_t s) {
     if (hipMalloc((void**)&d_st, (size_t)slots * NWAVES * 64) != hipSuccess) return -2;
     (void)hipMemset(d_st, 0, (size_t)slots * NWAVES * 64);
   }
-  hipLaunchKernelGGL(conv3x3_s2c64_cv1_kernel, dim3(grid), dim3(64 * NWAVES), LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, sx, sy, sb, d_st);
+  hipLaunchKernelGGL(conv3x3_s2c64_cv1_kernel, dim3(grid), dim3(64 * NWAVES), LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, sx, sy, sb, prio, d_st);
   if (st_path) {
     if (hipStreamSynchronize(s) != hipSuccess) return -2;
     const size_t nbytes = (size_t)grid * NWAVES * 64;

@@ -63,7 +63,7 @@ __device__ __forceinline__ void silu16(float16v& v) {
 }
 
 __global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs a, int tiles_x, int tiles_y, int ntiles, int sx, int sy,
-                                                                 int sb, unsigned long long* stamps) {
+                                                                 int sb, int prio, unsigned long long* stamps) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -233,6 +233,7 @@ __global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs
     acc[1] = (float16v)0.f;
     // fragments: one set per pixel block; the set of (half tap + 1, block) is read right behind the four MFMAs of
     // (half tap, block), i.e. four MFMAs (128 cycles) ahead of its use
+    if (prio) __builtin_amdgcn_s_setprio(1);
     half8 fr[2][4];
     auto read_half = [&](int ht, int pb) __attribute__((always_inline)) {   // ht = tap * 2 + channel half (64 channels = 4 slices)
       const int tap = ht >> 1, ta = tap >> 1, tc = tap & 1, c0 = (ht & 1) * 8;
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    if (prio) __builtin_amdgcn_s_setprio(0);
     PP_STAMP(3)   // reads + MFMAs
     if (wave >= 4) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -336,6 +338,7 @@ int launch_proto_phase_wreg(const ConvArgs& a, hipStream_t s) {
   int grid = 4 * ntiles <= slots ? 4 * ntiles : slots;  // a multiple of 4: every phase gets the same number of blocks
   const int step = grid >> 2;                          // tiles between two visits of a block (= blocks per phase)
   const int sx = step % tiles_x, sy = (step / tiles_x) % tiles_y, sb = step / tiles_x / tiles_y;
+  static const int prio = getenv("M355_PROTOR_PRIO") ? atoi(getenv("M355_PROTOR_PRIO")) : 0;   // experiment: s_setprio(1) around the K loop
   // diagnostic: M355_PROTOR_STAMPS=<file> -> per-wave section cycles of the LAST launch, written after a stream sync [sync]
   static const char* st_path = getenv("M355_PROTOR_STAMPS");
   static unsigned long long* d_st = nullptr;
@@ -343,7 +346,7 @@ int launch_proto_phase_wreg(const ConvArgs& a, hipStream_t s) {
     if (hipMalloc((void**)&d_st, (size_t)slots * NWAVES * 64) != hipSuccess) return -2;
     (void)hipMemset(d_st, 0, (size_t)slots * NWAVES * 64);
   }
-  hipLaunchKernelGGL(proto_phase_wreg_kernel, dim3(grid), dim3(64 * NWAVES), LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, sx, sy, sb, d_st);
+  hipLaunchKernelGGL(proto_phase_wreg_kernel, dim3(grid), dim3(64 * NWAVES), LDS_BYTES, s, a, tiles_x, tiles_y, ntiles, sx, sy, sb, prio, d_st);
   if (st_path) {
     if (hipStreamSynchronize(s) != hipSuccess) return -2;
     const size_t nbytes = (size_t)grid * NWAVES * 64;
