@@ -1608,6 +1608,8 @@ int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts) {
 
 int m355_get_raw_head(m355_engine* e, const float** d_raw, int* width) {
   if (!e || !d_raw || !width) return M355_ERR_INVALID;
+  if ((e->decode_fused || e->headtail_n == 3) && !e->keep_raw)
+    return const_cast<m355_engine*>(e)->fail(M355_ERR_STATE, "the raw head maps are not written (m355_set_keep_raw(e, 1) before the forward)");
   *d_raw = e->raw;
   *width = 64 + e->nc + e->nm;
   return M355_OK;

@@ -111,8 +111,10 @@ int m355_collect_op_times(m355_engine* e, double* ms_sum, long* counts);        
 int m355_get_raw_head(m355_engine* e, const float** d_raw, int* width);
 /* Asynchronous device-to-device copy of the first `batch` images of the raw head maps into d_out. */
 int m355_copy_raw_head(m355_engine* e, int batch, float* d_out, void* stream);
-/* With the decode fused into the head output convs (experiment switch M355_DECFUSE at m355_create time) the raw maps
- * are written besides the predictions only while keep != 0 (the default of a new engine); without it they always are. */
+/* keep != 0 (the default of a new engine): the raw maps are written and the decode is its own launch.  keep == 0 (the
+ * predict path): each head level's output convs and the decode of its rows run as one launch (csrc/head_tail.hip; same
+ * arithmetic, bit-identical predictions), the raw maps are NOT written and m355_get_raw_head / m355_copy_raw_head fail with
+ * M355_ERR_STATE.  (Models whose head does not fit that kernel -- nm != 32, nc > 32 -- always write the raw maps.) */
 int m355_set_keep_raw(m355_engine* e, int keep);
 
 /* Post-processing: batched NMS + mask assembly.
