@@ -183,6 +183,9 @@ int launch_stem(const StemArgs& a, hipStream_t s);
 // stem + model.1 + model.2.cv1 in one launch (conv_stem_s2c32.hip): a = the model.1 + cv1 launch, st = the stem launch
 bool stem_s2c32_ok(const ConvArgs& a, const StemArgs& st);
 int launch_stem_s2c32(const ConvArgs& a, const StemArgs& st, hipStream_t s);
+// the same launch with team X building the next tile's patch image while team Y runs the two convolutions (conv_stem_c2.hip)
+bool stem_s2c32_v2_ok(const ConvArgs& a, const StemArgs& st);
+int launch_stem_s2c32_v2(const ConvArgs& a, const StemArgs& st, hipStream_t s);
 
 int launch_sppf_pool(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy,
                      int B, int H, int W, int C, hipStream_t s);

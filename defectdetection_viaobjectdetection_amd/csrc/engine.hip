@@ -1062,6 +1062,9 @@ std::vector<std::pair<int, int>> frag_list(int k, int cin, int cout) {
   } else if (k == 3 && cin == 64 && cout == 128) {              // conv3x3_s2c64: [channel block m][36 slices]
     for (int m = 0; m < 4; ++m)
       for (int s = 0; s < 36; ++s) f.push_back({32 * m, 16 * s});
+  } else if (k == 3 && cin == 32 && cout == 64) {               // conv_stem_c2 (model.1): [channel block][18 slices], operand row order
+    for (int m = 0; m < 2; ++m)
+      for (int s = 0; s < 18; ++s) f.push_back({32 * m, 16 * s});
   } else if (k == 3 && cin == 32 && cout == 32) {               // c2f_c32: 18 slices
     for (int s = 0; s < 18; ++s) f.push_back({0, 16 * s});
   } else if (k == 1 && (cin == 128 || cin == 192 || cin == 256 || cin == 384 || cin == 512) && cout % 128 == 0 && cout <= 512) {
@@ -1175,6 +1178,14 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     if (p.composed && p.cout2 == 32 && p.cout == 128) {   // proto.cv3 as eight MFMA fragments (proto_phase_wreg.hip)
       std::vector<std::pair<int, int>> fl;
       for (int s = 0; s < 8; ++s) fl.push_back({0, 16 * s});
+      const auto fp = frag_pack(r2.data(), p.cout, fl, false);
+      if (!p.wf2) HIP_TRY(e, hipMalloc((void**)&p.wf2, fp.size() * sizeof(half_t)));
+      HIP_TRY(e, hipMemcpy(p.wf2, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    }
+    if (!p.composed && p.k == 3 && p.stride == 2 && p.cin == 32 && p.cout == 64 && p.cout2 == 64) {   // conv_stem_c2: [channel block][4 slices]
+      std::vector<std::pair<int, int>> fl;
+      for (int m = 0; m < 2; ++m)
+        for (int s = 0; s < 4; ++s) fl.push_back({32 * m, 16 * s});
       const auto fp = frag_pack(r2.data(), p.cout, fl, false);
       if (!p.wf2) HIP_TRY(e, hipMalloc((void**)&p.wf2, fp.size() * sizeof(half_t)));
       HIP_TRY(e, hipMemcpy(p.wf2, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
@@ -1311,10 +1322,11 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     if ((p.logical.size() == 1 || (p.l3 >= 0 && !p.composed && idx == p.logical[0])) && !p.diag && row0 == 0) {   // fragment-ordered copies for the weights-in-registers kernels
       const auto fl = frag_list(ci.k, ci.cin, ci.cout);
       if (!fl.empty()) {
-        const auto fp = frag_pack(rows.data(), p.Kpad, fl, false);
+        const bool stem_pair = ci.k == 3 && ci.cin == 32 && ci.cout == 64;   // its accumulators feed the 1x1's MFMAs directly
+        const auto fp = frag_pack(rows.data(), p.Kpad, fl, stem_pair);
         if (!p.wf) HIP_TRY(e, hipMalloc((void**)&p.wf, fp.size() * sizeof(half_t)));
         HIP_TRY(e, hipMemcpy(p.wf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
-        if (ci.k == 3 && ci.cin == 32) {
+        if (ci.k == 3 && ci.cin == 32 && !stem_pair) {
           const auto fo = frag_pack(rows.data(), p.Kpad, fl, true);
           if (!p.wf2) HIP_TRY(e, hipMalloc((void**)&p.wf2, fo.size() * sizeof(half_t)));
           HIP_TRY(e, hipMemcpy(p.wf2, fo.data(), fo.size() * sizeof(half_t), hipMemcpyHostToDevice));
@@ -1464,6 +1476,11 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           sa.w16 = (const half_t*)sp.stem_w; sa.bias = sp.bias;
           sa.y_bstride = (long)sto.H * sto.W * sto.C; sa.ldy = sto.C; sa.Cout = sp.cout;
           sa.y = sto.p + so.out.off + b0 * sa.y_bstride;
+          const bool stem2 = getenv("M355_NO_STEM2") == nullptr;  // two-team form (conv_stem_c2.hip, the default); read per launch: tests toggle it
+          if (stem2 && stem_s2c32_v2_ok(a, sa)) {
+            rc = launch_stem_s2c32_v2(a, sa, s);
+            break;
+          }
           if (stem_s2c32_ok(a, sa)) {
             rc = launch_stem_s2c32(a, sa, s);
             break;

@@ -380,6 +380,34 @@ def test_s2c32_patch_kernel_matches_the_im2col_form(cuda_device):
     assert e_raw <= 2e-3 and e_pr <= 2e-3
 
 
+@pytest.mark.parametrize("shape,batch", [((640, 640), 5), ((320, 384), 3)])
+def test_two_team_stem_launch_is_bit_identical(cuda_device, shape, batch):
+    """conv_stem_c2.hip (the default): model.0 + model.1 + model.2.cv1 with team X building the next tile's patch image while
+    team Y runs the two convolutions out of registers, against the lockstep launch (conv_stem_s2c32.hip, M355_NO_STEM2=1).  Same rounding points,
+    same K orders: identical bits in every network output."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(batch, seed=61)[:, :shape[0], :shape[1]].copy()).to(cuda_device)
+    eng = SegEngine("s", 1, shape, max_batch=batch)
+    assert any(k.startswith("stem+conv3x3_s2c32") for k in (o["kernel"] for o in eng.op_infos()))
+    eng.load_state_dict(sd)
+    outs = []
+    for two_team in (False, True):
+        if not two_team:
+            os.environ["M355_NO_STEM2"] = "1"
+        try:
+            p, q = eng.forward(imgs)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("M355_NO_STEM2", None)
+        outs.append((p.clone(), q.clone()))
+    eng.close()
+    assert torch.isfinite(outs[1][0]).all()
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_sub_batched_leading_ops_are_bit_identical(cuda_device):
     """M355_SUBBATCH=8 runs the large-map ops at the head of the graph over 8 images at a time (an experiment: the tensors
     then fit the Infinity Cache between producer and consumer; measured slower, so it is off by default).  Same
