@@ -471,21 +471,22 @@ def test_decode_in_the_head_epilogue_is_bit_identical(cuda_device):
     assert torch.equal(outs["fused_keep_raw"][2], outs["separate"][2])
 
 
-@pytest.mark.parametrize("shape,batch", [((608, 640), 7), ((640, 640), 3), ((320, 320), 5)])
-def test_head_levels_as_conv_plus_decode_launches(cuda_device, shape, batch):
+@pytest.mark.parametrize("shape,batch,nc", [((608, 640), 7, 1), ((640, 640), 3, 1), ((320, 320), 5, 1), ((320, 384), 4, 3), ((256, 256), 2, 20)])
+def test_head_levels_as_conv_plus_decode_launches(cuda_device, shape, batch, nc):
     """Predict path (raw head maps not kept): each head level's three output convs and the decode of its rows run as ONE
     launch (head_tail.hip) and head_decode_kernel is not launched; with the raw maps kept, the im2col launch per level + the
     decode launch.  Same arithmetic after the dot products (the decode is restated operation for operation); the dot products
-    themselves sum in another order (32x32x16 vs 16x16x32 MFMA), so the rows agree to fp32 rounding, not bit for bit.
+    themselves run on another MFMA shape (32x32x16 vs 16x16x32) and still come out identical: the rows are bit-identical.
     Shapes: 608 x 640 (76 x 80 map: fast row stores; 38 x 40 and 19 x 20: pixel blocks that cross image boundaries), three
-    images of 640 x 640 (a partial last tile on the 40 x 40 level), 320 x 320 (10 x 10 = 100 anchors per image)."""
+    images of 640 x 640 (a partial last tile on the 40 x 40 level), 320 x 320 (10 x 10 = 100 anchors per image); nc = 3 and 20:
+    class rows and the coefficient offset behind them (row width 4 + nc + 32: 39 floats has no 16-byte row alignment)."""
     from defectdetection_viaobjectdetection_amd.engine import SegEngine
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
-    sd = synthetic_state_dict("s", 1, seed=0)
+    sd = synthetic_state_dict("s", nc, seed=0)
     imgs = torch.from_numpy(synthetic_bscans(batch, seed=52)[:, :shape[0], :shape[1]].copy()).to(cuda_device)
     outs = {}
     for keep in (False, True):
-        eng = SegEngine("s", 1, shape, max_batch=batch, keep_raw=keep)
+        eng = SegEngine("s", nc, shape, max_batch=batch, keep_raw=keep)
         kinds = [o["kernel"] for o in eng.op_infos()]
         assert sum(k.startswith("head_tail") for k in kinds) == (0 if keep else 3)
         eng.load_state_dict(sd)
@@ -500,10 +501,11 @@ def test_head_levels_as_conv_plus_decode_launches(cuda_device, shape, batch):
     assert a.shape == b.shape and torch.isfinite(a).all()
     assert torch.equal(outs[False][1], outs[True][1])                       # prototypes: untouched
     d = (a - b).abs()
-    print(f"{shape} b{batch}: box max {float(d[..., :4].max()):.2e} px, score max {float(d[..., 4].max()):.2e}, "
-          f"coef max {float(d[..., 5:].max()):.2e}")
-    assert float(d[..., :4].max()) <= 2e-2 and float(d[..., 4].max()) <= 1e-5
-    assert float((d[..., 5:] / (1.0 + b[..., 5:].abs())).max()) <= 1e-4
+    print(f"{shape} b{batch} nc{nc}: box max {float(d[..., :4].max()):.2e} px, score max {float(d[..., 4:4 + nc].max()):.2e}, "
+          f"coef max {float(d[..., 4 + nc:].max()):.2e}")
+    # measured: identical bits on every shape (the MFMA sums of these K = 64 / 128 / 32 dot products come out the same in both
+    # shapes of the instruction); asserted as equality so that a change of either side shows
+    assert torch.equal(a, b)
 
 
 def test_stem_fused_into_the_patch_kernel_matches_the_two_launches(cuda_device):

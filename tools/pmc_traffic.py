@@ -16,7 +16,7 @@ LABELS = {
     "conv3x3_m32_kernel<128, 2>": "conv3x3_m32<128ch,8x16px>", "conv3x3_m32_kernel<64, 1>": "conv3x3_m32<64ch,8x16px>",
     "conv3x3_m32_kernel<64, 2>": "conv3x3_m32<64ch,16x16px>",
     "conv3x3_wide_kernel": "conv3x3_wide<128ch,16x16px>", "conv3x3_slab_kernel": "conv3x3_slab<64ch,rows>", "conv3x3_c32_kernel": "conv3x3_c32<32ch,16x16px>",
-    "stem_s2c32_cv1_kernel": "stem+conv3x3_s2c32<8x16px>+1x1", "conv_s2c32_cv1_kernel": "conv3x3_s2c32<8x16px>+1x1",
+    "stem_s2c32_cv1_kernel": "stem+conv3x3_s2c32<8x16px>+1x1", "stem_s2c32_cv1_v2_kernel": "stem+conv3x3_s2c32<8x16px>+1x1", "conv_s2c32_cv1_kernel": "conv3x3_s2c32<8x16px>+1x1",
     "stem_rows_kernel": "stem_conv<k3s2,u8,mfma>", "augment_kernel": "augment",
     "stem_kernel": "stem_conv<k3s2,u8,mfma>", "head_decode_kernel": "head_decode", "sppf_pool_kernel": "sppf_pool",
     "upsample2x_kernel": "upsample2x", "nms_kernel": "nms", "proto_masks_kernel": "proto_masks",
