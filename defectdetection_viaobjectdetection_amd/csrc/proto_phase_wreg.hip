@@ -40,7 +40,8 @@ constexpr int Z_OFF = NBUF * PATCH_BYTES;            // 128 pixels x 256 bytes: 
 constexpr int W3_OFF = Z_OFF + 128 * 256;            // eight fragments of the 1x1 (lane-linear)
 constexpr int BIAS_OFF = W3_OFF + 8 * 1024;          // [9][128] floats + 32 floats
 constexpr int STG_OFF = BIAS_OFF + 9 * 512 + 128;    // output staging: 4 waves x 32 pixels x 64 bytes
-constexpr int LDS_BYTES = STG_OFF + 4 * 2048;        // 133760
+constexpr int TAB_OFF = STG_OFF + 4 * 2048;          // DMA offset table: [39 pieces][64 lanes] ints
+constexpr int LDS_BYTES = TAB_OFF + 39 * 256;        // 143744
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
@@ -104,28 +105,41 @@ __global__ __launch_bounds__(512, 2) void proto_phase_wreg_kernel(const ConvArgs
     y0 = (rest - tb * tiles_y) * TH;
     x0 = tx * TW;
   };
+  // DMA offset table (tile independent): entry (piece g, lane l) = byte offset of that lane's 16 bytes from the patch origin,
+  // | 1 top patch row | 2 bottom row | 4 left column | 8 right column (low four bits: offsets are multiples of 16); -1 = lane
+  // past the patch.  Computed per issue, this was ~25 VALU instructions per piece (a division by 17 and two multiplies)
+  // beside the partner wave's K loop; from the table it is a ds_read and five.
+  for (int i = tid; i < NPIECES * 64; i += 64 * NWAVES) {
+    const int g = i >> 6, l = i & 63;
+    const int R = 4 * g + (l >> 4);
+    const int pr = R / PP, pc = R - pr * PP;
+    int e = -1;
+    if (R < PROWS)
+      e = (((pr * W + pc) * a.ldx + (((l ^ pc) & 15) << 3)) * 2) | (pr == 0 ? 1 : 0) | (pr == TH ? 2 : 0) | (pc == 0 ? 4 : 0) | (pc == TW ? 8 : 0);
+    ((int*)(smem + TAB_OFF))[i] = e;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();                        // (the table is read by the first issue below)
   auto issue_patch = [&](int tb, int y0, int x0, int buf) __attribute__((always_inline)) {
     const int oy = y0 - 1 + py, ox = x0 - 1 + px;
     const int origin = ((oy * W + ox) * a.ldx) * 2;
-    // lane id from mbcnt, opaque to the optimiser: the per-piece arithmetic stays in the loop (hoisted, it is spilled)
-    int r0;
-    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(r0));
-    const int lsl = r0 & 15;
+    // which border lines of the patch leave the map for this (tile, phase); bit 31 rejects the lanes past the patch
+    const int reject = (int)0x80000000 | (oy < 0 ? 1 : 0) | (oy + TH >= H ? 2 : 0) | (ox < 0 ? 4 : 0) | (ox + TW >= W ? 8 : 0);
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
     // Waves 0-3 (whose next stop is barrier A, where they wait for the other team's K loop) take 27 of the 39 pieces, waves
     // 4-7 (which go straight into their K loop: the critical path of the tile) the other 12.  Wave w of a team: g = g0 + w + 4 i.
     const int g0 = wave < 4 ? 0 : G_SPLIT, g1 = wave < 4 ? G_SPLIT : NPIECES;
-    r0 = 4 * (g0 + m) + (r0 >> 4);
+    const int* const tab = (const int*)(smem + TAB_OFF) + (g0 + m) * 64 + ln;
+    int e[P_IT];
+#pragma unroll
+    for (int i = 0; i < P_IT; ++i) e[i] = (g0 + m + 4 * i < g1) ? tab[256 * i] : -1;
 #pragma unroll
     for (int i = 0; i < P_IT; ++i) {
       const int g = g0 + m + 4 * i;
-      if (g < g1) {
-        const int R = r0 + 16 * i;
-        const int pr = __umul24(R, 3856) >> 16, pc = R - pr * PP;  // R / 17, R % 17 (exact for R < 200)
-        const int yy = oy + pr, xx = ox + pc;
-        const bool ok = R < PROWS && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W;
-        const int rel = (__mul24(__mul24(pr, W) + pc, a.ldx) + (((lsl ^ pc) & 15) << 3)) * 2;
-        dma16(rs_x, ok ? origin + rel : (int)0x80000000, tb * img_stride, smem + buf * PATCH_BYTES + g * 1024);   // out of range = zeros
-      }
+      if (g < g1)
+        dma16(rs_x, (e[i] & reject) == 0 ? origin + (e[i] & ~15) : (int)0x80000000, tb * img_stride,
+              smem + buf * PATCH_BYTES + g * 1024);   // out of range = zeros
     }
   };
   // ---- fragment offsets: pixel block pb = tile rows 4 half + 2 pb, + (n >> 4); column n & 15; tap (ta, tb) adds (ta, tb)
