@@ -2006,12 +2006,15 @@ int m355_conv_launch(const m355_conv_args* c, void* stream) {
   a.zero = (const half_t*)c->zero_page;
   int rc;
   // 1x1 convs of the training step (forward and input gradients) on conv1x1_wreg.hip where it applies (the weights are gathered
-  // from the packed rows: the per-step re-pack writes no fragment-ordered copy): 27.3 -> 27.0 ms per s-seg b64 step
+  // from the packed rows: the per-step re-pack writes no fragment-ordered copy): 27.4-27.5 -> 27.2-27.3 ms per s-seg b64 step on one box
   static const bool train_w1 = getenv("M355_NO_TRAIN_W1") == nullptr;
+  static const bool train_c32 = getenv("M355_NO_TRAIN_C32") == nullptr;   // 32 -> 32 3x3 layers on conv3x3_c32.hip: a further -0.1 ms
   if (!a.tmode && conv3x3_halo_ok(a))
     rc = launch_conv3x3_halo(a, 0, (hipStream_t)stream);
   else if (train_w1 && !a.tmode && conv1x1_wreg_ok(a))
     rc = launch_conv1x1_wreg(a, (hipStream_t)stream);
+  else if (train_c32 && !a.tmode && conv3x3_c32_ok(a) && conv_rows_covered(a, 32))
+    rc = launch_conv3x3_c32(a, (hipStream_t)stream);
   else
     rc = launch_conv_igemm(a, TILE_AUTO, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "conv launch failed: " + std::to_string(rc));
