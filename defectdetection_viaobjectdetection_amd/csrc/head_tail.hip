@@ -7,8 +7,9 @@
 // as reached from BscanBased/yolo8_seg_predict.py:8).
 //
 // The arithmetic after the MFMA is head_decode_kernel's, operation for operation (acc + bias; max, __expf, the two running sums
-// in bin order, IEEE division; (x1 + x2) * 0.5f * stride; 1 / (1 + __expf(-z))): the only difference to the two-launch path is the
-// summation order inside the K = 64 / 128 / 32 dot products (32x32x16 MFMA here, 16x16x32 there).
+// in bin order, IEEE division; (x1 + x2) * 0.5f * stride; 1 / (1 + __expf(-z))).  The dot products run on another MFMA shape
+// (32x32x16 here, 16x16x32 there) and still come out the same: the prediction rows are bit-identical to the two-launch path on
+// every shape of tests/test_engine_gpu.py::test_head_levels_as_conv_plus_decode_launches (nc = 1, 3, 20).
 //
 // Block = 8 waves, tile = 128 consecutive pixels of the level's flat (image, y, x) axis = 57 344 contiguous bytes, staged by
 // LDS-DMA in 56 pieces of 1 KiB into one of two buffers (the next tile streams in under this one); pixel rows of 448 bytes,
