@@ -85,6 +85,7 @@ SIGNATURES = {
     "m355_conv2d_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_int, C.c_int, C.c_int,
                                   C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "m355_c2f_c32_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
+    "m355_bneck_pair_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, C.c_int, _P]),
     "m355_conv2d_dgrad": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_conv2d_wgrad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_bn_silu_train_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P]),

@@ -173,6 +173,23 @@ struct C2fC32Args {
 bool c2f_c32_ok(const C2fC32Args& a);
 int launch_c2f_c32(const C2fC32Args& a, hipStream_t s);
 
+// Row-slab 3x3 kernels (conv3x3_planes.hip): a whole Bottleneck -- y = [x +] act(conv3x3(act(conv3x3(x, wa) + ba), wb) + bb), hidden
+// tensor in LDS -- or one 3x3 conv y = act(conv3x3(x, wb) + bb) [+ res].  Packed weight rows [rows][kpad], K = tap * Cin + cin.
+struct PlanesArgs {
+  const half_t* x; long x_bstride; int ldx;      // NHWC fp16 input slice (Cin channels)
+  int H, W, B, Cin, Cout;
+  const half_t *wa, *wb; int kpad_a, kpad_b, rows_a, rows_b;   // wa / ba: first conv of a pair (nullptr in single mode)
+  const float *ba, *bb;
+  half_t* y; long y_bstride; int ldy;
+  const half_t* res; long r_bstride; int ldr;    // optional residual (the shortcut of a Bottleneck: x itself)
+  int act;
+  unsigned long long* stamps;                    // diagnostic: 8 uint64 per wave (nullptr in production)
+};
+bool bneck_pair_ok(const PlanesArgs& a);
+int launch_bneck_pair(const PlanesArgs& a, hipStream_t s);
+bool conv3x3_planes_ok(const PlanesArgs& a);
+int launch_conv3x3_planes(const PlanesArgs& a, hipStream_t s);
+
 struct StemArgs {
   const uint8_t* x; int B, H, W;     // uint8 NHWC (B,H,W,3)
   const half_t* w16;                 // [Cout][32] fp16: k = (kh*3+kw)*3+ci, rows 27..31 zero; NOT scaled by 1/255

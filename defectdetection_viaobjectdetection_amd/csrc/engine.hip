@@ -1825,6 +1825,69 @@ int m355_c2f_c32_fwd(const void* d_x, int B, int H, int W, const float* h_wa, co
   return M355_OK;
 }
 
+int m355_bneck_pair_fwd(const void* d_x, int B, int H, int W, int C, int ldx, const float* h_wa, const float* h_ba, const float* h_wb,
+                        const float* h_bb, int shortcut, void* d_y, int ldy, void* stream) {
+  if (!d_x || !d_y || !h_wa || !h_ba || !h_wb || !h_bb) return set_err(M355_ERR_INVALID, "null pointer");
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldx < C || ldy < C) return set_err(M355_ERR_INVALID, "bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  const int kp = conv_kpad(C, 3), rows = conv_cout_pad(C);
+  std::vector<half_t> ra((size_t)rows * kp, (half_t)0.f), rb((size_t)rows * kp, (half_t)0.f);
+  pack_conv_rows(h_wa, C, C, 3, kp, 0, ra);
+  pack_conv_rows(h_wb, C, C, 3, kp, 0, rb);
+  std::vector<float> bias(2 * rows, 0.f);
+  for (int i = 0; i < C; ++i) { bias[i] = h_ba[i]; bias[rows + i] = h_bb[i]; }
+  half_t* dw = nullptr;
+  float* db = nullptr;
+  HIP_TRYG(hipMalloc((void**)&dw, 2 * ra.size() * sizeof(half_t)));
+  HIP_TRYG(hipMalloc((void**)&db, bias.size() * sizeof(float)));
+  HIP_TRYG(hipMemcpy(dw, ra.data(), ra.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(dw + ra.size(), rb.data(), rb.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
+  PlanesArgs a{};
+  a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * ldx; a.ldx = ldx; a.H = H; a.W = W; a.B = B; a.Cin = C; a.Cout = C;
+  a.wa = dw; a.wb = dw + ra.size(); a.kpad_a = a.kpad_b = kp; a.rows_a = a.rows_b = rows;
+  a.ba = db; a.bb = db + rows;
+  a.y = (half_t*)d_y; a.y_bstride = (long)H * W * ldy; a.ldy = ldy; a.act = 1;
+  if (shortcut) { a.res = a.x; a.r_bstride = a.x_bstride; a.ldr = ldx; }
+  unsigned long long* d_st = nullptr;
+  const char* st_path = getenv("M355_STAMPS");
+  const size_t st_n = (size_t)256 * 4 * 8;
+  if (st_path) {
+    HIP_TRYG(hipMalloc((void**)&d_st, st_n * 8));
+    HIP_TRYG(hipMemset(d_st, 0, st_n * 8));
+    a.stamps = d_st;
+  }
+  const bool ok = bneck_pair_ok(a);
+  int rc = ok ? launch_bneck_pair(a, s) : -1;
+  if (const char* reps = getenv("M355_BNECK_REPS")) {   // diagnostic: average launch time over n back-to-back launches -> stderr
+    const int n = atoi(reps);
+    hipEvent_t e0, e1;
+    if (rc == 0 && n > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+      (void)hipEventRecord(e0, s);
+      for (int i = 0; i < n && rc == 0; ++i) rc = launch_bneck_pair(a, s);
+      (void)hipEventRecord(e1, s);
+      (void)hipEventSynchronize(e1);
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, e0, e1);
+      fprintf(stderr, "bneck_pair B=%d %dx%d C=%d: %.2f us per launch (%d launches)\n", B, H, W, C, ms * 1e3f / n, n);
+      (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+  }
+  const hipError_t se = hipStreamSynchronize(s);
+  if (st_path && se == hipSuccess && rc == 0) {
+    std::vector<unsigned long long> hst(st_n);
+    (void)hipMemcpy(hst.data(), d_st, st_n * 8, hipMemcpyDeviceToHost);
+    FILE* f = fopen(st_path, "wb");
+    if (f) { fwrite(hst.data(), 8, st_n, f); fclose(f); }
+  }
+  if (d_st) (void)hipFree(d_st);
+  (void)hipFree(dw); (void)hipFree(db);
+  if (!ok) return set_err(M355_ERR_INVALID, "bneck_pair: shape not eligible (C in {64, 128}, slab geometry must fit LDS)");
+  if (rc != 0) return set_err(M355_ERR_HIP, "bneck_pair launch failed: " + std::to_string(rc));
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("bneck_pair kernel: ") + hipGetErrorString(se));
+  return M355_OK;
+}
+
 int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const float* h_w, int cout, int k, int stride,
                       void* d_dx, void* stream) {
   if (!d_dy || !h_w || !d_dx) return set_err(M355_ERR_INVALID, "null pointer");

@@ -141,6 +141,14 @@ int m355_conv2d_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int cin, cons
 int m355_c2f_c32_fwd(const void* d_x_f16_nhwc, int B, int H, int W, const float* h_wa, const float* h_ba,
                      const float* h_wb, const float* h_bb, const float* h_wc, const float* h_bc, int shortcut,
                      void* d_y_f16_nhwc, void* stream);
+/* A whole C2f Bottleneck (upstream nn.modules.block.Bottleneck with e = 1.0: cv1 3x3 -> cv2 3x3, optional shortcut)
+ * in ONE launch (csrc/conv3x3_planes.hip): t = SiLU(conv3x3(x; wa) + ba) stays in LDS (rounded to fp16 exactly where the
+ * two-launch form stores it), y = SiLU(conv3x3(t; wb) + bb) (+ x if shortcut).  d_x fp16 NHWC (B,H,W,ldx) of which the first C
+ * channels are x; d_y fp16 NHWC (B,H,W,ldy), first C channels written; C in {64, 128}; h_wa / h_wb fp32 (C,C,3,3) and
+ * biases fp32 (C): HOST pointers (BN folded), packed + uploaded here.  Shapes whose row slabs do not fit LDS are refused
+ * (M355_ERR_INVALID).  [sync] */
+int m355_bneck_pair_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int C, int ldx, const float* h_wa, const float* h_ba,
+                        const float* h_wb, const float* h_bb, int shortcut, void* d_y_f16_nhwc, int ldy, void* stream);
 /* Data gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2, no bias) (SURVEY A13 backward): dY fp16 NHWC
  * (B,Ho,Wo,cout) -> dX fp16 NHWC (B,H,W,cin).  Runs on the same implicit-GEMM kernel: stride 1 = convolution
  * with the spatially flipped, channel-transposed weights; stride 2 = transposed-stride gather.  h_w is the

@@ -1,0 +1,95 @@
+"""The fused Bottleneck launch (csrc/conv3x3_planes.hip: m.cv1 -> m.cv2 (+ shortcut) of a C2f block in one launch, hidden tensor in
+LDS) through the C-ABI against a plain PyTorch fp32 reference with the engine's rounding points: fp16 input and weights,
+fp32 accumulation, the hidden tensor t rounded to fp16 where the two-launch form stores it, the output rounded to fp16."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _h(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ref(x, wa, ba, wb, bb, shortcut):
+    r16 = lambda t: t.half().float()
+    t = r16(F.silu(F.conv2d(x, wa, ba, padding=1)))
+    y = F.silu(F.conv2d(t, wb, bb, padding=1))
+    return y + x if shortcut else y
+
+
+CASES = [
+    # B, H, W, C, shortcut, channel offset of x / y inside a wider NHWC buffer (None: dense tensors)
+    (2, 40, 40, 128, True, None),      # the stride-16 level at 640 x 640: slabs of 5 rows, 8 per image
+    (3, 20, 20, 128, False, None),     # ... at 320 x 320: slabs of 10 rows; no shortcut (the neck's form)
+    (2, 80, 80, 64, True, None),       # the stride-8 level at 640 x 640: 64 hidden channels, two pixel groups of waves
+    (3, 40, 40, 64, False, None),
+    (1, 13, 37, 128, True, None),      # ragged: last slab shorter, odd width
+    (2, 23, 51, 64, True, None),
+    (5, 40, 40, 128, True, (128, 256, 384)),   # x = channels [128, 256) and y = channels [256, 384) of ONE 384-channel buffer (C2f's concat)
+    (40, 40, 40, 128, True, None),     # 320 slabs over 256 blocks: two tiles per block, the prefetch across tiles
+    (34, 80, 80, 64, False, None),     # 680 slabs: three tiles for some blocks
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cc,shortcut,cat", CASES)
+def test_bneck_pair_against_torch(cuda_device, B, H, W, Cc, shortcut, cat):
+    from defectdetection_viaobjectdetection_amd import _capi
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cc)
+    r16 = lambda t: t.half().float()
+    x = (torch.randn((B, Cc, H, W), generator=g) * 0.8).half()
+    wa = r16(torch.randn((Cc, Cc, 3, 3), generator=g) * (2.0 / (9 * Cc)) ** 0.5)
+    wb = r16(torch.randn((Cc, Cc, 3, 3), generator=g) * (2.0 / (9 * Cc)) ** 0.5)
+    ba, bb = (torch.randn(Cc, generator=g) * 0.3 for _ in range(2))
+    arrs = [t.numpy().astype(np.float32).copy() for t in (wa, ba, wb, bb)]
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if cat is None:
+        xd = x.permute(0, 2, 3, 1).contiguous().to(cuda_device)
+        yd = torch.full((B, H, W, Cc), float("nan"), dtype=torch.float16, device=cuda_device)
+        xp, yp, ldx, ldy = xd.data_ptr(), yd.data_ptr(), Cc, Cc
+    else:
+        xo, yo, tot = cat
+        buf = torch.full((B, H, W, tot), 7.0, dtype=torch.float16, device=cuda_device)
+        buf[..., xo:xo + Cc] = x.permute(0, 2, 3, 1).to(cuda_device)
+        xp, yp, ldx, ldy = buf.data_ptr() + 2 * xo, buf.data_ptr() + 2 * yo, tot, tot
+
+    def run(dst):
+        _capi.check(_capi.lib.m355_bneck_pair_fwd(C.c_void_p(xp), B, H, W, Cc, ldx, _h(arrs[0]), _h(arrs[1]), _h(arrs[2]), _h(arrs[3]),
+                                                  int(shortcut), C.c_void_p(dst), ldy, st))
+    run(yp)
+    if cat is None:
+        got = yd.float().cpu().permute(0, 3, 1, 2)
+    else:
+        got = buf[..., yo:yo + Cc].float().cpu().permute(0, 3, 1, 2)
+        other = torch.cat((buf[..., :xo], buf[..., yo + Cc:]), -1)
+        assert bool((other == 7.0).all()) and torch.equal(buf[..., xo:xo + Cc].cpu(), x.permute(0, 2, 3, 1))   # nothing else touched
+    torch.set_num_threads(max(torch.get_num_threads(), 8))
+    want = _ref(x.float(), wa, ba, wb, bb, shortcut)
+    assert torch.isfinite(got).all()
+    rel = float((got - want).norm() / want.norm())
+    worst = float((got - want.half().float()).abs().max())
+    print(f"B={B} {H}x{W} C={Cc} shortcut={shortcut}: rel-L2 {rel:.2e}, max |d| vs the fp16-rounded reference {worst:.2e}")
+    assert rel <= 1e-3
+    assert worst <= 2e-2      # a hidden value on the other side of an fp16 rounding boundary moves an output by ~1 ulp of ~4
+    if cat is None:           # twice = the same bits
+        yd2 = torch.empty_like(yd)
+        run(yd2.data_ptr())
+        assert torch.equal(yd, yd2)
+
+
+def test_bneck_pair_refuses_what_it_cannot_tile(cuda_device):
+    from defectdetection_viaobjectdetection_amd import _capi
+    z = np.zeros(96 * 96 * 9, np.float32)
+    x = torch.zeros((1, 16, 16, 96), dtype=torch.float16, device=cuda_device)
+    rc = _capi.lib.m355_bneck_pair_fwd(C.c_void_p(x.data_ptr()), 1, 16, 16, 96, 96, _h(z), _h(z), _h(z), _h(z), 1,
+                                       C.c_void_p(x.data_ptr()), 96, None)
+    assert rc != 0            # 96 hidden channels: no instance
+    z = np.zeros(128 * 128 * 9, np.float32)
+    x = torch.zeros((1, 4, 700, 128), dtype=torch.float16, device=cuda_device)
+    rc = _capi.lib.m355_bneck_pair_fwd(C.c_void_p(x.data_ptr()), 1, 4, 700, 128, 128, _h(z), _h(z), _h(z), _h(z), 1,
+                                       C.c_void_p(x.data_ptr()), 128, None)
+    assert rc != 0            # a 700-pixel row does not fit the pixel blocks of one slab

@@ -1,0 +1,25 @@
+"""Launch time of the fused Bottleneck kernel (csrc/conv3x3_planes.hip) through m355_bneck_pair_fwd's diagnostic loop
+(M355_BNECK_REPS) and its in-kernel stamps (M355_STAMPS).  Usage: python tools/bneck_bench.py [B]"""
+import ctypes as C, os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["M355_BNECK_REPS"] = "50"
+os.environ["M355_STAMPS"] = "/tmp/bneck_stamps.bin"
+from defectdetection_viaobjectdetection_amd import _capi
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+h = lambda a: a.ctypes.data_as(C.c_void_p)
+for (H, W, Cc) in ((40, 40, 128), (80, 80, 64), (20, 20, 128)):
+    x = torch.randn(B, H, W, Cc, device="cuda").half()
+    y = torch.empty_like(x)
+    w = (np.random.default_rng(0).standard_normal((Cc, Cc, 3, 3)) * (2.0 / (9 * Cc)) ** 0.5).astype(np.float32)
+    b = np.zeros(Cc, np.float32)
+    rc = _capi.lib.m355_bneck_pair_fwd(C.c_void_p(x.data_ptr()), B, H, W, Cc, Cc, h(w), h(b), h(w), h(b), 1, C.c_void_p(y.data_ptr()), Cc, None)
+    if rc != 0:
+        print((H, W, Cc), "refused")
+        continue
+    s = np.fromfile("/tmp/bneck_stamps.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+    s = s[s[:, 0] > 0]
+    d = np.diff(s[:, :6], axis=1)
+    names = ["prologue", "conv1", "transition", "conv2", "epilogue(last tile)"]
+    print(f"  {(B, H, W, Cc)}: waves {len(s)}; median cycles: " + ", ".join(f"{n} {int(np.median(d[:, i]))}" for i, n in enumerate(names)) +
+          f"; life {int(np.median(s[:, 5] - s[:, 0]))}; flops {2 * 2 * 9 * Cc * Cc * B * H * W / 1e9:.1f} G")
