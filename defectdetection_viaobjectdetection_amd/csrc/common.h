@@ -174,17 +174,20 @@ bool c2f_c32_ok(const C2fC32Args& a);
 int launch_c2f_c32(const C2fC32Args& a, hipStream_t s);
 
 // Row-slab 3x3 kernels (conv3x3_planes.hip): a whole Bottleneck -- y = [x +] act(conv3x3(act(conv3x3(x, wa) + ba), wb) + bb), hidden
-// tensor in LDS -- or one 3x3 conv y = act(conv3x3(x, wb) + bb) [+ res].  Packed weight rows [rows][kpad], K = tap * Cin + cin.
+// tensor in LDS -- or one 3x3 conv y = act(conv3x3(x, wb) + bb) [+ res].  Weights as MFMA A fragments in K-loop order
+// (planes_frag_pack in engine.hip): fragment ((cb * NP + p) * 9 + tap) * 2 + s = rows 32 cb .. + 31 (plain row permutation),
+// K = tap * Cin + 32 p + 16 s .. + 15; 1 KiB each, lane-linear.
 struct PlanesArgs {
   const half_t* x; long x_bstride; int ldx;      // NHWC fp16 input slice (Cin channels)
   int H, W, B, Cin, Cout;
-  const half_t *wa, *wb; int kpad_a, kpad_b, rows_a, rows_b;   // wa / ba: first conv of a pair (nullptr in single mode)
+  const half_t *wfa, *wfb; int cblocks_a, cblocks_b;   // fragment-ordered weights and their 32-channel blocks; wfa / ba: first conv of a pair (nullptr in single mode)
   const float *ba, *bb;
   half_t* y; long y_bstride; int ldy;
   const half_t* res; long r_bstride; int ldr;    // optional residual (the shortcut of a Bottleneck: x itself)
   int act;
   unsigned long long* stamps;                    // diagnostic: 8 uint64 per wave (nullptr in production)
 };
+bool bneck_pair_shape_ok(int C, int H, int W);
 bool bneck_pair_ok(const PlanesArgs& a);
 int launch_bneck_pair(const PlanesArgs& a, hipStream_t s);
 bool conv3x3_planes_ok(const PlanesArgs& a);

@@ -43,7 +43,6 @@ namespace {
 typedef float float16v __attribute__((ext_vector_type(16)));
 
 constexpr int ROWB = 64;      // bytes per LDS row: 32 channels of one pixel / 32 K values of one weight row
-constexpr int NWS = 4;        // weight ring slots
 constexpr int LDS_MAX = 160 * 1024;
 
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, char* lds) {
@@ -57,7 +56,7 @@ struct PlanesGeom {
   int NP, NPo;              // input planes (Cin / 32); planes of the hidden tensor (pair) = WC
   int tiles_ch;             // single mode: output channel tiles
   int ntiles;
-  int off_x, off_w, off_s;  // LDS byte offsets: input ring, weight ring, scratch piece
+  int off_x, off_s;         // LDS byte offsets: input ring, one spare KiB behind it (reads of never-stored pixel blocks may run past a slot)
 };
 
 template <int WC_, int NPB1_, int NPB2_, bool PAIR_, int PPS_>
@@ -66,8 +65,6 @@ struct PCfg {
   static constexpr bool PAIR = PAIR_;
   static constexpr int NB1 = WP * NPB1, NB2 = WP * NPB2;
   static constexpr int NPB = NPB1 > NPB2 ? NPB1 : NPB2;
-  static constexpr int WSTAGE = 32 * WC * ROWB;   // bytes per weight stage
-  static constexpr int W_IT = WC / 2;             // weight DMA instructions per wave and stage
   static constexpr int PIT = 6 * PPS;             // input pieces per wave and plane (issued in steps 0 .. 5)
   static_assert(WC == 2 || WC == 4, "channel blocks per block");
 };
@@ -75,119 +72,121 @@ struct PCfg {
 template <class C>
 struct PState {
   float16v acc[C::NPB];
-  half8 fa[2], fb[2][C::NPB];
-  int ta;                     // A fragment: LDS byte offset inside a weight stage, K slice 0 (slice 1: ^ 32 -- chunk (2 s + h) ^ swizzle)
+  half8 wa[3][2];             // weight fragments (MFMA A operands) of three consecutive steps, straight from global memory
+  half8 fb[2][C::NPB];
   int tb[9];                  // B fragment: LDS byte offset inside a plane for (tap, slice 0), pixel block 0 of this wave
   int pvoff[C::PIT];          // per-lane source offsets of the input pieces of the slab the loader is on
-  int wvoff[C::W_IT];
-  __amdgpu_buffer_rsrc_t rs_x, rs_wa, rs_wb;
+  __amdgpu_buffer_rsrc_t rs_x;
   char* smem;
-  int wave;
-  // consumer side
-  int wslot;                  // ring slot of the current step's weight stage
+  int wave, lane16;
   int pcur, pnext;            // LDS byte offset of the current / the next phase's plane
-  bool last_phase;            // no step follows the phase's last one without a gap (transition / epilogue in between)
-  // weight loader cursor: stage (conv, plane, tap) that step g issues = the stage of step g + 3
-  int lw_conv, lw_p, lw_t, lw_left, lw_ch0, lw_ch0_next;
-  bool drain;                 // a weight issue was skipped (end of the block's stream): counted waits no longer hold
-  // input pieces of the phase
-  bool pieces;                // this phase streams an input plane
-  int px_soff, px_dst;        // scalar source offset (image, plane) and LDS byte offset of the target slot
-  int cin2, kpa, kpb;         // bytes per tap in a weight row; bytes per weight row (first / second conv)
-  int NP;
-  int off_w, off_s, npieces;
+  // weight cursor: the fragments step g loads = those of step g + 2.  A convolution's fragments of one channel block are
+  // contiguous in K-loop order (plane, tap, slice): the cursor is a byte offset that advances by 2 KiB per step.
+  // weight stream: the fragments step g loads are those of step g + 2.  A convolution's fragments of one channel block are
+  // contiguous in K-loop order (plane, tap, slice), 2 KiB per step: steps 0 .. 6 of a phase load at wp_cur + 2 KiB * (tap + 2),
+  // steps 7, 8 the first two steps of the NEXT phase (wp_next: next plane, next convolution or next tile) -- both set per phase.
+  const char *wp_cur, *wp_next;
+  int wblock;                 // bytes of one channel block's fragments of one convolution (2 KiB * 9 * planes)
+  // input pieces of the phase: this wave issues piece m (LDS KiB wave + 4 m of the target slot) in step m / PPS; pieces from
+  // nreal on are zero fills of the spare KiB (a phase that streams nothing: nreal = 0)
+  int nreal, px_soff, px_dst; // px_dst: LDS byte offset of this wave's piece 0
+  int off_s;
 };
 
-// s_waitcnt vmcnt(n) lgkmcnt(0) with a compile-time n (n < 64)
-template <int N>
-__device__ __forceinline__ void wait_vm_lgkm0() {
-  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+// fp16 rounding of an epilogue value, opaque to mul + cvt fusion like m355_to_half, but not volatile: the sixteen values of a
+// pixel block are independent chains the scheduler may interleave (the volatile form cost 210 s_nops per transition)
+__device__ __forceinline__ half_t to_half_rn(float v) {
+  asm("" : "+v"(v));
+  return (half_t)v;
 }
 
-// One K step: tap TAP of the current phase.  Entering, fragment set 0 holds K slice 0 of this step.
-//   NPBC = pixel blocks of this convolution.
+// One K step: tap TAP of the current phase.  Entering: st.wa[TAP % 3] holds (or is about to receive) this step's two weight
+// fragments, st.wa[(TAP + 1) % 3] the next step's (in flight), fragment set 0 of fb holds K slice 0 of this step.
+// Straight-line code (no branch: the input pieces of a phase that streams nothing go to the spare KiB with out-of-range
+// offsets, i.e. as zero fills), so that the MFMAs, the LDS reads and the vector-memory issues of a step are ONE scheduling
+// region and the sched_group_barriers below can pin  MFMA, ds_read, (vmem)  triples: with one wave per SIMD every
+// instruction that is not issued beside an executing MFMA is matrix-pipe idle time.
 template <class C, int NPBC, int TAP>
-__device__ __forceinline__ void planes_step(PState<C>& st) {
-  constexpr int NT = (TAP + 1) % 9;
-  char* const wb = st.smem + st.off_w + st.wslot * C::WSTAGE;
-  // K slice 1 of this step
-  st.fa[1] = *(const half8*)(wb + (st.ta ^ 32));
+__device__ __forceinline__ void planes_step(PState<C>& st, int wc) {
+  constexpr int NT = (TAP + 1) % 9, CUR = TAP % 3, LD = (TAP + 2) % 3;
+  constexpr int NPC = TAP < 6 ? C::PPS : 0;             // input pieces of this step
+  static_assert(NPBC >= 3 + NPC, "pixel blocks per wave");
+  // weight fragments of step g + 2 (always issued: past the block's last step the pointers keep walking valid memory)
+  const char* const wsrc = (TAP < 7 ? st.wp_cur + (TAP + 2) * 2048 : st.wp_next + (TAP - 7) * 2048) + st.lane16;
+  // K slice 0: MFMAs interleaved with the reads of slice 1, the two weight loads and the input pieces
+  const int b1 = st.pcur + (st.tb[TAP] ^ 32);
 #pragma unroll
-  for (int k = 0; k < NPBC; ++k) st.fb[1][k] = *(const half8*)(st.smem + st.pcur + (st.tb[TAP] ^ 32) + k * (2048 * C::WP));
-#pragma unroll
-  for (int k = 0; k < NPBC; ++k) st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.fa[0], st.fb[0][k], st.acc[k], 0, 0, 0);
-  __builtin_amdgcn_sched_barrier(0);
-  // this wave's part of the NEXT step's stage has landed (issued two steps ago; younger: the pieces of that step, the
-  // weights and the pieces of the previous step), its own LDS reads have returned
-  {
-    constexpr int P2 = (TAP >= 2 && TAP - 2 < 6) ? C::PPS : 0;
-    constexpr int P1 = (TAP >= 1 && TAP - 1 < 6) ? C::PPS : 0;
-    if (st.drain) wait_vm_lgkm0<0>();
-    else if (st.pieces) wait_vm_lgkm0<P2 + C::W_IT + P1>();
-    else wait_vm_lgkm0<C::W_IT>();
-  }
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_sched_barrier(0);
-  const int nslot = (st.wslot + 1) & (NWS - 1);
-  // K slice 0 of the next step
-  if (TAP < 8 || !st.last_phase) {
-    char* const wn = st.smem + st.off_w + nslot * C::WSTAGE;
-    const int pn = TAP < 8 ? st.pcur : st.pnext;
-    st.fa[0] = *(const half8*)(wn + st.ta);
-#pragma unroll
-    for (int k = 0; k < NPBC; ++k) st.fb[0][k] = *(const half8*)(st.smem + pn + st.tb[NT] + k * (2048 * C::WP));
-  }
-  // weights of step g + 3 into the slot of step g - 1
-  if (st.lw_left > 0) {
-    char* dst = st.smem + st.off_w + ((st.wslot + 3) & (NWS - 1)) * C::WSTAGE + st.wave * (C::W_IT * 1024);
-    const int soff = st.lw_ch0 + st.lw_t * st.cin2 + st.lw_p * 64;
-    if (C::PAIR && st.lw_conv == 0) {
-#pragma unroll
-      for (int i = 0; i < C::W_IT; ++i) dma16(st.rs_wa, st.wvoff[i], soff, dst + i * 1024);
-    } else {
-#pragma unroll
-      for (int i = 0; i < C::W_IT; ++i) dma16(st.rs_wb, st.wvoff[i], soff, dst + i * 1024);
-    }
-    --st.lw_left;
-    if (++st.lw_t == 9) {
-      st.lw_t = 0;
-      if (++st.lw_p == st.NP) {   // next convolution; past a tile's last one: the next tile's channel block
-        st.lw_p = 0;
-        if (C::PAIR) st.lw_conv ^= 1;
-        if (!C::PAIR || st.lw_conv == 0) st.lw_ch0 = st.lw_ch0_next;
-      }
-    }
-  } else {
-    st.drain = true;
-  }
-  // input pieces of the phase's target plane: PPS per step in steps 0 .. 5 (a piece past the plane goes to the scratch KiB
-  // with an out-of-range offset, so that the number of vector-memory operations per step is a compile-time constant)
-  if (TAP < 6 && st.pieces) {
-#pragma unroll
-    for (int i = 0; i < C::PPS; ++i) {
-      const int m = TAP * C::PPS + i;
-      const int k = st.wave + 4 * m;
-      const bool real = k < st.npieces;
-      dma16(st.rs_x, real ? st.pvoff[m] : (int)0x80000000, st.px_soff, st.smem + (real ? st.px_dst + k * 1024 : st.off_s));
+  for (int k = 0; k < NPBC; ++k) {
+    st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.wa[CUR][0], st.fb[0][k], st.acc[k], 0, 0, 0);
+    st.fb[1][k] = *(const half8*)(st.smem + b1 + k * (2048 * C::WP));
+    if (k == 0) st.wa[LD][0] = *(const half8*)wsrc;
+    if (k == 1) st.wa[LD][1] = *(const half8*)(wsrc + 1024);
+    if (k >= 2 && k < 2 + NPC) {
+      const int m = TAP * C::PPS + (k - 2);
+      const bool real = m < st.nreal;
+      dma16(st.rs_x, real ? st.pvoff[m] : (int)0x80000000, st.px_soff, st.smem + (real ? st.px_dst + m * 4096 : st.off_s));
     }
   }
-  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int k = 0; k < NPBC; ++k) st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.fa[1], st.fb[1][k], st.acc[k], 0, 0, 0);
-  st.wslot = nslot;
+  for (int k = 0; k < NPBC; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
+    if (k < 2 + NPC) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (TAP == 8) {
+    // phase end: this wave's pieces of the next plane have landed (issued in steps 0 .. 5; younger: the six weight loads of steps
+    // 6, 7, 8), then every wave's
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // K slice 1: MFMAs interleaved with the reads of the next step's slice 0
+  const int b0 = (TAP < 8 ? st.pcur : st.pnext) + st.tb[NT];
+#pragma unroll
+  for (int k = 0; k < NPBC; ++k) {
+    st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.wa[CUR][1], st.fb[1][k], st.acc[k], 0, 0, 0);
+    st.fb[0][k] = *(const half8*)(st.smem + b0 + k * (2048 * C::WP));
+  }
+#pragma unroll
+  for (int k = 0; k < NPBC; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// SiLU of eight values, the five instructions of m355_silu (x * rcp(1 + exp2(-log2e * x)): the same bits) issued as five rows
+// of eight independent instructions.  The compiler schedules the 16 chains of a pixel block one after the other through one
+// temporary (register pressure heuristics at 256 VGPRs): every instruction then waits for its predecessor's result and each
+// transcendental needs an s_nop before its use -- 54 cycles per value measured; interleaved it is the issue cost, 28.
+__device__ __forceinline__ void silu8(float (&v)[8]) {
+  float t[8];
+  asm("v_mul_f32 %8, 0xbfb8aa3b, %0\n\tv_mul_f32 %9, 0xbfb8aa3b, %1\n\tv_mul_f32 %10, 0xbfb8aa3b, %2\n\tv_mul_f32 %11, 0xbfb8aa3b, %3\n\t"
+      "v_mul_f32 %12, 0xbfb8aa3b, %4\n\tv_mul_f32 %13, 0xbfb8aa3b, %5\n\tv_mul_f32 %14, 0xbfb8aa3b, %6\n\tv_mul_f32 %15, 0xbfb8aa3b, %7\n\t"
+      "v_exp_f32 %8, %8\n\tv_exp_f32 %9, %9\n\tv_exp_f32 %10, %10\n\tv_exp_f32 %11, %11\n\t"
+      "v_exp_f32 %12, %12\n\tv_exp_f32 %13, %13\n\tv_exp_f32 %14, %14\n\tv_exp_f32 %15, %15\n\t"
+      "v_add_f32 %8, 1.0, %8\n\tv_add_f32 %9, 1.0, %9\n\tv_add_f32 %10, 1.0, %10\n\tv_add_f32 %11, 1.0, %11\n\t"
+      "v_add_f32 %12, 1.0, %12\n\tv_add_f32 %13, 1.0, %13\n\tv_add_f32 %14, 1.0, %14\n\tv_add_f32 %15, 1.0, %15\n\t"
+      "v_rcp_f32 %8, %8\n\tv_rcp_f32 %9, %9\n\tv_rcp_f32 %10, %10\n\tv_rcp_f32 %11, %11\n\t"
+      "v_rcp_f32 %12, %12\n\tv_rcp_f32 %13, %13\n\tv_rcp_f32 %14, %14\n\tv_rcp_f32 %15, %15\n\t"
+      "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %9\n\tv_mul_f32 %2, %2, %10\n\tv_mul_f32 %3, %3, %11\n\t"
+      "v_mul_f32 %4, %4, %12\n\tv_mul_f32 %5, %5, %13\n\tv_mul_f32 %6, %6, %14\n\tv_mul_f32 %7, %7, %15"
+      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+        "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]));
 }
 
 template <class C, int NPBC>
-__device__ __forceinline__ void planes_phase(PState<C>& st) {
-  planes_step<C, NPBC, 0>(st);
-  planes_step<C, NPBC, 1>(st);
-  planes_step<C, NPBC, 2>(st);
-  planes_step<C, NPBC, 3>(st);
-  planes_step<C, NPBC, 4>(st);
-  planes_step<C, NPBC, 5>(st);
-  planes_step<C, NPBC, 6>(st);
-  planes_step<C, NPBC, 7>(st);
-  planes_step<C, NPBC, 8>(st);
+__device__ __forceinline__ void planes_phase(PState<C>& st, int wc) {
+  planes_step<C, NPBC, 0>(st, wc);
+  planes_step<C, NPBC, 1>(st, wc);
+  planes_step<C, NPBC, 2>(st, wc);
+  planes_step<C, NPBC, 3>(st, wc);
+  planes_step<C, NPBC, 4>(st, wc);
+  planes_step<C, NPBC, 5>(st, wc);
+  planes_step<C, NPBC, 6>(st, wc);
+  planes_step<C, NPBC, 7>(st, wc);
+  planes_step<C, NPBC, 8>(st, wc);
 }
 
 struct PTile {
@@ -225,18 +224,12 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   PState<C> st;
   st.smem = smem;
   st.wave = wave;
-  st.NP = g.NP;
-  st.off_w = g.off_w;
+  st.lane16 = lane * 16;
   st.off_s = g.off_s;
-  st.npieces = g.npieces;
-  st.cin2 = a.Cin * 2;
-  st.kpa = a.kpad_a * 2;
-  st.kpb = a.kpad_b * 2;
-  st.drain = false;
+  st.wblock = 2048 * 9 * g.NP;
+  const int nreal_wave = (g.npieces - wave + 3) / 4;     // pieces of a plane this wave issues
   const int img_stride = (int)a.x_bstride * 2;
   st.rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((a.B - 1) * a.x_bstride + (long)H * W * a.ldx) * 2, 0x00020000);
-  st.rs_wb = __builtin_amdgcn_make_buffer_rsrc((void*)a.wb, 0, a.rows_b * a.kpad_b * 2, 0x00020000);
-  st.rs_wa = C::PAIR ? __builtin_amdgcn_make_buffer_rsrc((void*)a.wa, 0, a.rows_a * a.kpad_a * 2, 0x00020000) : st.rs_wb;
 
   // input pieces of a tile: piece k = wave + 4 m covers LDS rows 16 k .. 16 k + 15 = storage indices; index j = rj * PW + cj is
   // image pixel (y0 - HALO + rj, cj - 1); outside the image (and the shared zero column cj = 0) the offset fails the range
@@ -254,21 +247,7 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
       st.pvoff[m] = ok ? ((iy * W + ix) * a.ldx + lc * 8) * 2 : (int)0x80000000;
     }
   };
-  // weight stage rows: piece k = wave * W_IT + i covers stage rows 16 k .. 16 k + 15; MFMA row 8 q + 4 h + i of a 32-row
-  // block holds channel 16 h + 4 q + i, so that accumulator register r of lane-half h is channel 16 h + r
-#pragma unroll
-  for (int i = 0; i < C::W_IT; ++i) {
-    const int r = 16 * (wave * C::W_IT + i) + lrow;
-    const int rho = r & 31;
-    const int chl = (r & ~31) + 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
-    const int lc = lchunk ^ ((r >> 2) & 3);
-    st.wvoff[i] = chl * st.kpb + lc * 16;   // both convs of a pair have the same row pitch (same Cin): one offset serves both
-  }
-  {
-    const int r = wc * 32 + l31;
-    st.ta = r * ROWB + ((h ^ ((r >> 2) & 3)) << 4);
-  }
-  // B fragment offsets of the nine taps: storage index of this lane's pixel of block 0 + the tap's shift (D)
+  // B fragment offsets of the nine taps: storage index of this lane's pixel of block 0 + the tap's shift
   const int idx0 = 32 * wp + l31;
   auto tap_offsets = [&](int dshift) __attribute__((always_inline)) {
 #pragma unroll
@@ -293,36 +272,25 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   PTile cur = decode(vb), nxt = cur;
   bool more = vb + nwg < ntiles;
   if (more) nxt = decode(vb + nwg);
-  const int stages_per_tile = (C::PAIR ? 2 : 1) * 9 * g.NP;
-  {
-    int mine = 0;
-    for (int v = vb; v < ntiles; v += nwg) ++mine;
-    st.lw_left = mine * stages_per_tile;
-  }
-  st.lw_conv = 0; st.lw_p = 0; st.lw_t = 0;
-  st.lw_ch0 = cur.ch * st.kpb;
-  st.lw_ch0_next = nxt.ch * st.kpb;
+  const char* const wbase_a = C::PAIR ? (const char*)a.wfa + (long)wc * st.wblock : nullptr;   // pair: this wave's channel block in either conv
+  const char* wbase_b = (const char*)a.wfb + (long)(cur.ch / 32 + wc) * st.wblock;               // second / only conv, this tile
+  const char* wbase_b_next = (const char*)a.wfb + (long)(nxt.ch / 32 + wc) * st.wblock;          // ... the block's next tile
 
-  // ---- prologue: input plane 0 into slot 0, weight stages 0, 1, 2
+  // ---- prologue: input plane 0 into slot 0, the weight fragments of steps 0 and 1
   piece_offsets(cur);
 #pragma unroll
   for (int m = 0; m < C::PIT; ++m) {
     const int k = wave + 4 * m;
     if (k < g.npieces) dma16(st.rs_x, st.pvoff[m], cur.b * img_stride, smem + g.off_x + k * 1024);
   }
-  st.wslot = 0;
-  for (int sgi = 0; sgi < 3; ++sgi) {
-    char* dst = smem + g.off_w + sgi * C::WSTAGE + wave * (C::W_IT * 1024);
-    const int soff = st.lw_ch0 + st.lw_t * st.cin2 + st.lw_p * 64;
+  {
+    const char* w0 = (C::PAIR ? wbase_a : wbase_b) + st.lane16;
 #pragma unroll
-    for (int i = 0; i < C::W_IT; ++i) dma16(C::PAIR ? st.rs_wa : st.rs_wb, st.wvoff[i], soff, dst + i * 1024);
-    --st.lw_left;
-    if (++st.lw_t == 9) {
-      st.lw_t = 0;
-      if (++st.lw_p == st.NP) { st.lw_p = 0; st.lw_conv ^= 1; }
+    for (int sgi = 0; sgi < 2; ++sgi) {
+      st.wa[sgi][0] = *(const half8*)(w0 + sgi * 2048);
+      st.wa[sgi][1] = *(const half8*)(w0 + sgi * 2048 + 1024);
     }
   }
-  // the tail of the intermediate planes is never written by the transition: nothing to clear (32 * NB1 > (R + 2) * PW)
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (a.stamps) stamp[1] = __builtin_amdgcn_s_memtime();
@@ -333,55 +301,72 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
 
   while (true) {
     // =========================== first convolution (pair mode): R + 2 rows of the hidden tensor ===========================
-    if (C::PAIR) {
+    if constexpr (C::PAIR) {
       tap_offsets(-1);
 #pragma unroll
       for (int k = 0; k < C::NPB1; ++k)
 #pragma unroll
         for (int j = 0; j < 16; ++j) st.acc[k][j] = 0.f;
-      // slice 0 of step 0 (plane 0 of the tile, weight stage in st.wslot)
+      // slice 0 of step 0 (plane 0 of the tile)
       {
         const int p0 = g.off_x + (xg & 1) * xslot;
-        st.fa[0] = *(const half8*)(smem + g.off_w + st.wslot * C::WSTAGE + st.ta);
 #pragma unroll
         for (int k = 0; k < C::NPB1; ++k) st.fb[0][k] = *(const half8*)(smem + p0 + st.tb[0] + k * (2048 * C::WP));
       }
       for (int p = 0; p < g.NP; ++p) {
         st.pcur = g.off_x + (xg & 1) * xslot;
-        st.pnext = g.off_x + ((xg + 1) & 1) * xslot;
-        st.last_phase = p == g.NP - 1;
-        st.pieces = p + 1 < g.NP;   // stream plane p + 1 of this tile into the other slot
+        st.pnext = p + 1 < g.NP ? g.off_x + ((xg + 1) & 1) * xslot : st.pcur;
+        st.nreal = p + 1 < g.NP ? nreal_wave : 0;   // stream plane p + 1 of this tile into the other slot
         st.px_soff = cur.b * img_stride + (p + 1) * 64;
-        st.px_dst = st.pnext;
-        planes_phase<C, C::NPB1>(st);
+        st.px_dst = g.off_x + ((xg + 1) & 1) * xslot + wave * 1024;
+        st.wp_cur = wbase_a + p * (9 * 2048);
+        st.wp_next = p + 1 < g.NP ? st.wp_cur + 9 * 2048 : wbase_b;
+        planes_phase<C, C::NPB1>(st, wc);
         ++xg;
       }
       if (a.stamps) stamp[2] = __builtin_amdgcn_s_memtime();
-      // ---- transition: bias is in the accumulators; SiLU, zero outside the image (the zero padding of the second conv), fp16,
-      // into plane wc of the hidden tensor
+      // ---- transition: bias, SiLU, fp16 into plane wc of the hidden tensor; then the zero padding of the second conv is
+      // written OVER it (the shared pad column ci = 0 of every row, the rows outside the image): no per-value select
       if (more) piece_offsets(nxt);   // every piece of this tile has been issued: the loader moves on
       {
         const float16v bv = load_bias(a.ba, 0);
+        char* const plane = smem + wc * iplane;
 #pragma unroll
         for (int k = 0; k < C::NPB1; ++k) {
           const int i = 32 * (wp + C::WP * k) + l31;
-          const int ri = i / PW, ci = i - ri * PW;
-          const int iy = cur.y0 - 1 + ri;
-          const bool ok = ci >= 1 && ri < R + 2 && (unsigned)iy < (unsigned)H;
           half8 o[2];
 #pragma unroll
-          for (int hh = 0; hh < 2; ++hh)
+          for (int hh = 0; hh < 2; ++hh) {
+            float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float v = st.acc[k][hh * 8 + j] + bv[hh * 8 + j];
-              if (a.act) v = m355_silu(v);
-              o[hh][j] = m355_to_half(ok ? v : 0.f);
-            }
-          char* rowp = smem + wc * iplane + i * ROWB;
+            for (int j = 0; j < 8; ++j) v[j] = st.acc[k][hh * 8 + j] + bv[hh * 8 + j];
+            silu8(v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[hh][j] = (half_t)v[j];
+          }
+          char* rowp = plane + i * ROWB;
           const int sw = (i >> 2) & 3;
           *(half8*)(rowp + (((2 * h) ^ sw) << 4)) = o[0];
           *(half8*)(rowp + (((2 * h + 1) ^ sw) << 4)) = o[1];
           __builtin_amdgcn_sched_barrier(0);   // one pixel block at a time: 16 accumulator values in VGPRs, not 144
+        }
+        // zero padding (this wave's writes are ordered: LDS operations of one wave complete in order).  Only the wp == 0 wave of a
+        // channel block does it -- after a barrier when a second pixel group wrote parts of the plane.
+        if (C::WP > 1) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        if (wp == 0) {
+          const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+          // pad column: rows ri * PW, ri = 0 .. R + 2 (the last one is the pad behind the last row); 4 lanes x 16 bytes each
+          for (int e = lane; e < 4 * (R + 3); e += 64) *(half8*)(plane + (e >> 2) * PW * ROWB + ((e & 3) << 4)) = z;
+          // rows outside the image: only the first and the last slab of an image have any
+#pragma unroll 1
+          for (int ri = 0; ri < R + 2; ++ri) {
+            const int iy = cur.y0 - 1 + ri;
+            if ((unsigned)iy < (unsigned)H) continue;
+            for (int e = lane; e < 4 * PW; e += 64) *(half8*)(plane + (ri * PW + (e >> 2)) * ROWB + ((e & 3) << 4)) = z;
+          }
         }
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -397,73 +382,90 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
         for (int j = 0; j < 16; ++j) st.acc[k][j] = 0.f;
       {
         const int p0 = C::PAIR ? 0 : g.off_x + (xg & 1) * xslot;
-        st.fa[0] = *(const half8*)(smem + g.off_w + st.wslot * C::WSTAGE + st.ta);
 #pragma unroll
         for (int k = 0; k < C::NPB2; ++k) st.fb[0][k] = *(const half8*)(smem + p0 + st.tb[0] + k * (2048 * C::WP));
       }
       const int npl = C::PAIR ? g.NPo : g.NP;
       for (int p = 0; p < npl; ++p) {
-        st.last_phase = p == npl - 1;
         bool pieces = false;
         if (C::PAIR) {
           st.pcur = p * iplane;
-          st.pnext = (p + 1) * iplane;
+          st.pnext = p + 1 < npl ? (p + 1) * iplane : st.pcur;
           if (p == 0 && more) {   // plane 0 of the next tile into the slot the next tile starts with
             pieces = true;
             st.px_soff = nxt.b * img_stride;
-            st.px_dst = g.off_x + (xg & 1) * xslot;
+            st.px_dst = g.off_x + (xg & 1) * xslot + wave * 1024;
           }
         } else {
           st.pcur = g.off_x + (xg & 1) * xslot;
           st.pnext = g.off_x + ((xg + 1) & 1) * xslot;
+          st.px_dst = st.pnext + wave * 1024;
           if (p + 1 < g.NP) {
             pieces = true;
             st.px_soff = cur.b * img_stride + (p + 1) * 64;
-            st.px_dst = st.pnext;
           } else if (more) {
             piece_offsets(nxt);
             pieces = true;
             st.px_soff = nxt.b * img_stride;
-            st.px_dst = st.pnext;
+          } else {
+            st.pnext = st.pcur;
           }
           ++xg;
         }
-        st.pieces = pieces;
-        planes_phase<C, C::NPB2>(st);
+        st.nreal = pieces ? nreal_wave : 0;
+        st.wp_cur = wbase_b + p * (9 * 2048);
+        st.wp_next = p + 1 < npl ? st.wp_cur + 9 * 2048 : (C::PAIR ? wbase_a : wbase_b_next);
+        planes_phase<C, C::NPB2>(st, wc);
       }
       if (a.stamps) stamp[4] = __builtin_amdgcn_s_memtime();
-      // ---- epilogue: bias, SiLU, residual, fp16, two 16-byte stores per pixel
-      const float16v bv2 = load_bias(a.bb, cur.ch);
-#pragma unroll
-      for (int k = 0; k < C::NPB2; ++k) {
+      // ---- epilogue: bias, SiLU, residual, fp16, two 16-byte stores per pixel.  Pixel q -> (row, column) by an exact float
+      // division (q < 2^11); every residual load is issued before the first value is touched.
+      {
 #pragma clang fp contract(off)
-        const int q = 32 * (wp + C::WP * k) + l31;
-        const int r = q / PW, c = q - r * PW;
-        const int yy = cur.y0 + r;
-        const bool ok = c < W && r < R && yy < H;
-        const long pix = (long)yy * W + c;
+        const float rpw = 1.0f / (float)PW;
         const int c0 = cur.ch + wc * 32 + 16 * h;
+        const bool ch_ok = c0 + 16 <= a.Cout;
+        int off_y[C::NPB2], off_r[C::NPB2];
+        half8 rv[C::NPB2][2];
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          if (!ok || c0 + hh * 8 + 8 > a.Cout) continue;
-          float v[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = st.acc[k][hh * 8 + j] + bv2[hh * 8 + j];
-          if (a.act) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = m355_silu(v[j]);
+        for (int k = 0; k < C::NPB2; ++k) {
+          const int q = 32 * (wp + C::WP * k) + l31;
+          const int r = (int)(((float)q + 0.5f) * rpw), c = q - r * PW;
+          const int yy = cur.y0 + r;
+          const bool ok = c < W && r < R && yy < H && ch_ok;
+          const int pix = yy * W + c;
+          off_y[k] = ok ? pix * a.ldy + c0 : -1;
+          off_r[k] = pix * a.ldr + c0;
+          if (a.res && ok) {
+            const half_t* rp = a.res + (long)cur.b * a.r_bstride + off_r[k];
+            rv[k][0] = *(const half8*)rp;
+            rv[k][1] = *(const half8*)(rp + 8);
           }
-          if (a.res) {
-            const half8 rv = *(const half8*)(a.res + (long)cur.b * a.r_bstride + pix * a.ldr + c0 + hh * 8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)rv[j];
-          }
-          half8 o;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = m355_to_half(v[j]);
-          *(half8*)(a.y + (long)cur.b * a.y_bstride + pix * a.ldy + c0 + hh * 8) = o;
         }
-        __builtin_amdgcn_sched_barrier(0);
+        const float16v bv2 = load_bias(a.bb, cur.ch);
+        half_t* const yb = a.y + (long)cur.b * a.y_bstride;
+#pragma unroll
+        for (int k = 0; k < C::NPB2; ++k) {
+          half8 o[2];
+#pragma unroll
+          for (int hh = 0; hh < 2; ++hh) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = st.acc[k][hh * 8 + j] + bv2[hh * 8 + j];
+            silu8(v);
+            if (a.res) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += (float)rv[k][hh][j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[hh][j] = to_half_rn(v[j]);
+          }
+          if (off_y[k] >= 0) {
+            *(half8*)(yb + off_y[k]) = o[0];
+            *(half8*)(yb + off_y[k] + 8) = o[1];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
     if (!more) break;
@@ -471,9 +473,10 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
     cur = nxt;
     more = vb + nwg < ntiles;
     if (more) nxt = decode(vb + nwg);
-    st.lw_ch0_next = nxt.ch * st.kpb;
-    // every wave has left the previous tile's hidden planes / last input plane before the next tile overwrites them: the
-    // barriers of the next tile's first steps order that (the transition is > NP phases away; input slots alternate)
+    wbase_b = wbase_b_next;
+    wbase_b_next = (const char*)a.wfb + (long)(nxt.ch / 32 + wc) * st.wblock;
+    // (the next tile's first phases end in barriers before anything of this tile's LDS state is overwritten: input slots
+    // alternate, the hidden planes are rewritten only in the next transition)
   }
   if (a.stamps && lane == 0) {
     stamp[5] = __builtin_amdgcn_s_memtime();
@@ -497,7 +500,7 @@ bool planes_geometry(const PlanesArgs& a, PlanesGeom* g) {
     const int npieces = ((R + 2 * HALO) * PW + 1 + 15) / 16;
     if (npieces > 4 * C::PIT) continue;
     const int inter = C::PAIR ? C::WC * 32 * C::NB1 * ROWB : 0;
-    if (inter + 2 * npieces * 1024 + NWS * C::WSTAGE + 1024 > LDS_MAX) continue;
+    if (inter + 2 * npieces * 1024 + 1024 > LDS_MAX) continue;
     break;
   }
   if (R < 1) return false;
@@ -513,16 +516,15 @@ bool planes_geometry(const PlanesArgs& a, PlanesGeom* g) {
   g->tiles_ch = C::PAIR ? 1 : (a.Cout + 32 * C::WC - 1) / (32 * C::WC);
   g->ntiles = a.B * nslab * g->tiles_ch;
   g->off_x = C::PAIR ? C::WC * g->irows * ROWB : 0;
-  g->off_w = g->off_x + 2 * g->xrows * ROWB;
-  g->off_s = g->off_w + NWS * C::WSTAGE;
+  g->off_s = g->off_x + 2 * g->xrows * ROWB;
   return g->off_s + 1024 <= LDS_MAX;
 }
 
 bool planes_common_ok(const PlanesArgs& a) {
-  if (!a.x || !a.y || !a.wb || !a.bb || a.B < 1 || a.H < 1 || a.W < 2) return false;
-  if (a.Cin % 32 || a.Cin < 64 || a.ldx % 8 || a.ldy % 8 || a.kpad_b % 8 || a.kpad_b < 9 * a.Cin) return false;
+  if (!a.x || !a.y || !a.wfb || !a.bb || a.B < 1 || a.H < 1 || a.W < 2) return false;
+  if (a.Cin % 32 || a.Cin < 64 || a.ldx % 8 || a.ldy % 8 || !a.act) return false;   // (every 3x3 conv of the graphs has SiLU: the kernels apply it unconditionally)
   if (((long)(a.B - 1) * a.x_bstride + (long)a.H * a.W * a.ldx) * 2 >= (1L << 31)) return false;   // one buffer descriptor over the input
-  if ((long)a.rows_b * a.kpad_b * 2 >= (1L << 31)) return false;
+  if ((long)a.cblocks_b * (a.Cin / 32) * 18 * 1024 >= (1L << 31)) return false;                        // and one over the fragments
   return true;
 }
 
@@ -550,11 +552,20 @@ using S64 = PCfg<2, 0, 4, false, 1>;    // single conv, 64-channel tiles: 20 x 2
 
 }  // namespace
 
+// Shape-only eligibility (graph construction): an instance exists for C hidden channels and its row slabs fit LDS.
+bool bneck_pair_shape_ok(int C, int H, int W) {
+  PlanesArgs a{};
+  a.H = H; a.W = W; a.B = 1; a.Cin = a.Cout = C;
+  PlanesGeom g;
+  if (C == 128) return planes_geometry<P128>(a, &g);
+  if (C == 64) return planes_geometry<P64>(a, &g);
+  return false;
+}
+
 // A whole Bottleneck (two 3x3 convs, hidden = in = out channels) in one launch.
 bool bneck_pair_ok(const PlanesArgs& a) {
-  if (!planes_common_ok(a) || !a.wa || !a.ba) return false;
-  if (a.Cin != a.Cout || a.kpad_a != a.kpad_b || a.rows_a < a.Cin || a.rows_b < a.Cin) return false;
-  if ((long)a.rows_a * a.kpad_a * 2 >= (1L << 31)) return false;
+  if (!planes_common_ok(a) || !a.wfa || !a.ba) return false;
+  if (a.Cin != a.Cout || a.cblocks_a * 32 < a.Cin || a.cblocks_b * 32 < a.Cin) return false;
   PlanesGeom g;
   if (a.Cin == 128) return planes_geometry<P128>(a, &g);
   if (a.Cin == 64) return planes_geometry<P64>(a, &g);
@@ -571,7 +582,7 @@ int launch_bneck_pair(const PlanesArgs& a, hipStream_t s) {
 // One 3x3 conv (+ SiLU, + residual) over row slabs, 64-channel output tiles.
 bool conv3x3_planes_ok(const PlanesArgs& a) {
   if (!planes_common_ok(a)) return false;
-  if ((a.Cin / 32) % 2 || a.Cout % 8 || a.rows_b < (a.Cout + 63) / 64 * 64) return false;   // (the input ring alternates slots across tiles: even plane count)
+  if ((a.Cin / 32) % 2 || a.Cout % 8 || a.cblocks_b * 32 < (a.Cout + 63) / 64 * 64) return false;   // (the input ring alternates slots across tiles: even plane count)
   PlanesGeom g;
   return planes_geometry<S64>(a, &g);
 }

@@ -39,12 +39,13 @@ struct ConvLayer {
   // fused group: logical convs that were merged into this physical conv (head first-layer fusion)
 };
 
-enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_PHASE, OP_POOL, OP_UP, OP_DECODE, OP_ADOWN, OP_C2F32 };
+enum OpKind { OP_STEM, OP_CONV, OP_CONVT, OP_PHASE, OP_POOL, OP_UP, OP_DECODE, OP_ADOWN, OP_C2F32, OP_PAIR };
 
 struct Op {
   OpKind kind;
   int conv = -1;       // physical conv index (phys_)
   int conv2 = -1, conv3 = -1;   // OP_C2F32: Bottleneck.cv2 and C2f.cv2 (conv = Bottleneck.cv1); `in` = the [y0, y1] slice C2f.cv1 wrote
+                                // OP_PAIR: conv = Bottleneck.cv1, conv2 = Bottleneck.cv2 in one launch (conv3x3_planes.hip); out2 = the hidden tensor of the two-launch fallback
   int shortcut = 0;
   Slice in, out, res;  // tensor slices
   Slice in2;           // upsample read-through: channels [0, in2.c) of `in` come from this half-resolution slice
@@ -94,6 +95,7 @@ struct PhysConv {
   // conv3x3_c128r / conv1x1_wreg / c2f_c32's first conv), wf2 = operand row order (c2f_c32's second conv); nullptr = not built
   half_t* wf = nullptr;
   half_t* wf2 = nullptr;
+  int planes = 0;            // wf = the K-loop fragment order of the row-slab 3x3 kernels (planes_frag_pack)
 };
 
 }  // namespace
@@ -262,6 +264,22 @@ struct Builder {
     for (int j = 0; j < n; ++j) {
       const int tmp = tensor(H, W, c);
       const Slice src{cat, (1 + j) * c, c};
+      if (bneck_pair_shape_ok(c, H, W) && !getenv("M355_NO_PAIR")) {
+        // the whole Bottleneck in one launch, hidden tensor in LDS (conv3x3_planes.hip); `tmp` only serves the two-launch
+        // fallback of a call the kernel's 31-bit buffer offsets cannot address
+        const std::string mn = name + ".m." + std::to_string(j);
+        const int la = logical(mn + ".cv1", c, c, 3, 1, 1, 0, 1), lb = logical(mn + ".cv2", c, c, 3, 1, 1, 0, 1);
+        Op op{};
+        op.kind = OP_PAIR;
+        op.conv = phys_from({la}); op.conv2 = phys_from({lb});
+        e->phys[op.conv].planes = e->phys[op.conv2].planes = 1;
+        op.in = src; op.out = Slice{cat, (2 + j) * c, c}; op.out2 = Slice{tmp, 0, c};
+        op.shortcut = shortcut ? 1 : 0;
+        if (shortcut) op.res = src;
+        e->macs += (double)H * W * 2.0 * 9 * c * c;
+        e->ops.push_back(op);
+        continue;
+      }
       conv(name + ".m." + std::to_string(j) + ".cv1", src, Slice{tmp, 0, c}, 3, 1);
       conv(name + ".m." + std::to_string(j) + ".cv2", Slice{tmp, 0, c}, Slice{cat, (2 + j) * c, c}, 3, 1,
            shortcut ? src : Slice());
@@ -703,7 +721,7 @@ void plan_sub_batches(m355_engine* e) {
   if (e->sub_batch <= 0 || getenv("M355_NO_SUBBATCH")) { e->sub_batch = 0; return; }
   int n = 0;
   for (const Op& op : e->ops) {
-    if ((op.kind != OP_STEM && op.kind != OP_CONV && op.kind != OP_C2F32) || op.lane != 0 || op.record || !op.wait_ops.empty() || op.out_ext != 0) break;
+    if ((op.kind != OP_STEM && op.kind != OP_CONV && op.kind != OP_C2F32 && op.kind != OP_PAIR) || op.lane != 0 || op.record || !op.wait_ops.empty() || op.out_ext != 0) break;
     const Tensor& to = e->tensors[op.out.t];
     if (to.H * 8 < e->desc.in_h) break;
     ++n;
@@ -969,6 +987,16 @@ void annotate_ops(m355_engine* e) {
         op.wbytes = ((double)pa.cout * pa.Kpad + (double)pb.cout * pb.Kpad + (double)pc.cout * pc.Kpad) * 2;
         break;
       }
+      case OP_PAIR: {
+        const Tensor& t = e->tensors[op.in.t];
+        const PhysConv &pa = e->phys[op.conv], &pb = e->phys[op.conv2];
+        snprintf(op.kernel, sizeof(op.kernel), "bneck_pair<%dch>", pa.cout);
+        snprintf(op.layer, sizeof(op.layer), "%s+cv2", e->convs[pa.logical[0]].name);
+        op.flops = 2.0 * t.H * t.W * (pa.macs_px + pb.macs_px);
+        op.bytes = (double)t.H * t.W * (op.in.c + op.out.c) * 2;   // the shortcut re-reads the input slice from L2
+        op.wbytes = ((double)pa.cout * pa.Kpad + (double)pb.cout * pb.Kpad) * 2;
+        break;
+      }
       case OP_POOL: {
         const Tensor& t = e->tensors[op.in.t];
         snprintf(op.kernel, sizeof(op.kernel), "sppf_pool");
@@ -1072,6 +1100,17 @@ std::vector<std::pair<int, int>> frag_list(int k, int cin, int cout) {
       for (int s = 0; s < cin / 16; ++s) f.push_back({32 * cb, 16 * s});
   }
   return f;
+}
+
+// Fragment order of the row-slab 3x3 kernels (conv3x3_planes.hip): [channel block cb][input plane p][tap][K slice s], plain row
+// permutation -- the K-loop order of one wave, so that its weight stream is one linearly advancing pointer (2 KiB per step).
+std::vector<half_t> planes_frag_pack(const half_t* rows, int Kpad, int cin, int cblocks) {
+  std::vector<std::pair<int, int>> fl;
+  for (int cb = 0; cb < cblocks; ++cb)
+    for (int p = 0; p < cin / 32; ++p)
+      for (int tap = 0; tap < 9; ++tap)
+        for (int s = 0; s < 2; ++s) fl.push_back({32 * cb, tap * cin + 32 * p + 16 * s});
+  return frag_pack(rows, Kpad, fl, false);
 }
 
 }  // namespace
@@ -1319,7 +1358,14 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
         }
       }
     }
-    if ((p.logical.size() == 1 || (p.l3 >= 0 && !p.composed && idx == p.logical[0])) && !p.diag && row0 == 0) {   // fragment-ordered copies for the weights-in-registers kernels
+    if (p.planes && p.logical.size() == 1 && ci.k == 3 && ci.cin % 32 == 0) {   // K-loop fragment order of the row-slab kernels, channel blocks padded with zero rows
+      const int cbl = (ci.cout + 63) / 64 * 2;
+      std::vector<half_t> padded((size_t)cbl * 32 * p.Kpad, (half_t)0.f);
+      std::copy(rows.begin(), rows.end(), padded.begin());
+      const auto fp = planes_frag_pack(padded.data(), p.Kpad, ci.cin, cbl);
+      if (!p.wf) HIP_TRY(e, hipMalloc((void**)&p.wf, fp.size() * sizeof(half_t)));
+      HIP_TRY(e, hipMemcpy(p.wf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    } else if ((p.logical.size() == 1 || (p.l3 >= 0 && !p.composed && idx == p.logical[0])) && !p.diag && row0 == 0) {   // fragment-ordered copies for the weights-in-registers kernels
       const auto fl = frag_list(ci.k, ci.cin, ci.cout);
       if (!fl.empty()) {
         const bool stem_pair = ci.k == 3 && ci.cin == 32 && ci.cout == 64;   // its accumulators feed the 1x1's MFMAs directly
@@ -1512,6 +1558,41 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         a.y = to.p + op.out.off + b0 * a.y_bstride;
         a.shortcut = op.shortcut;
         rc = launch_c2f_c32(a, s);
+        break;
+      }
+      case OP_PAIR: {
+        const Tensor& ti = e->tensors[op.in.t];
+        const Tensor& to = e->tensors[op.out.t];
+        const PhysConv &pa = e->phys[op.conv], &pb = e->phys[op.conv2];
+        PlanesArgs a{};
+        a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C; a.H = ti.H; a.W = ti.W; a.B = Bq; a.Cin = pa.cin; a.Cout = pb.cout;
+        a.x = ti.p + op.in.off + b0 * a.x_bstride;
+        a.wfa = pa.wf; a.wfb = pb.wf; a.cblocks_a = (pa.cout + 63) / 64 * 2; a.cblocks_b = (pb.cout + 63) / 64 * 2;
+        a.ba = pa.bias; a.bb = pb.bias; a.act = 1;
+        a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
+        a.y = to.p + op.out.off + b0 * a.y_bstride;
+        if (op.shortcut) { a.res = a.x; a.r_bstride = a.x_bstride; a.ldr = a.ldx; }
+        if (bneck_pair_ok(a)) {
+          rc = launch_bneck_pair(a, s);
+          break;
+        }
+        // two launches through the hidden tensor (a batch whose buffers exceed the kernel's 31-bit offsets)
+        const Tensor& tt = e->tensors[op.out2.t];
+        for (int half = 0; half < 2 && rc == 0; ++half) {
+          const PhysConv& p = half ? pb : pa;
+          ConvArgs c{};
+          const Tensor& ci_ = half ? tt : ti;
+          const Tensor& co_ = half ? to : tt;
+          const int ioff = half ? op.out2.off : op.in.off, ooff = half ? op.out.off : op.out2.off;
+          c.x = ci_.p + ioff; c.x_bstride = (long)ci_.H * ci_.W * ci_.C; c.ldx = ci_.C;
+          c.Hi = ti.H; c.Wi = ti.W; c.Cin = p.cin; c.w = p.w; c.Kpad = p.Kpad; c.bias = p.bias; c.zero = e->zero; c.act = 1;
+          c.ksize = 3; c.stride = 1; c.pad = 1; c.Ho = ti.H; c.Wo = ti.W; c.Cout = p.cout;
+          c.y = co_.p + ooff; c.y_bstride = (long)co_.H * co_.W * co_.C; c.ldy = co_.C;
+          c.M = Bq * c.Ho * c.Wo;
+          c.x += b0 * c.x_bstride; c.y = (half_t*)c.y + b0 * c.y_bstride;
+          if (half && op.shortcut) { c.res = a.x; c.r_bstride = a.x_bstride; c.ldr = a.ldx; }
+          rc = conv3x3_halo_ok(c) ? launch_conv3x3_halo(c, 0, s) : launch_conv_igemm(c, TILE_AUTO, s);
+        }
         break;
       }
       case OP_POOL: {
@@ -1830,22 +1911,24 @@ int m355_bneck_pair_fwd(const void* d_x, int B, int H, int W, int C, int ldx, co
   if (!d_x || !d_y || !h_wa || !h_ba || !h_wb || !h_bb) return set_err(M355_ERR_INVALID, "null pointer");
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || ldx < C || ldy < C) return set_err(M355_ERR_INVALID, "bad shape");
   hipStream_t s = (hipStream_t)stream;
-  const int kp = conv_kpad(C, 3), rows = conv_cout_pad(C);
+  if (C % 32) return set_err(M355_ERR_INVALID, "C must be a multiple of 32");
+  const int kp = conv_kpad(C, 3), rows = conv_cout_pad(C), cbl = C / 32;
   std::vector<half_t> ra((size_t)rows * kp, (half_t)0.f), rb((size_t)rows * kp, (half_t)0.f);
   pack_conv_rows(h_wa, C, C, 3, kp, 0, ra);
   pack_conv_rows(h_wb, C, C, 3, kp, 0, rb);
+  const std::vector<half_t> fa = planes_frag_pack(ra.data(), kp, C, cbl), fb = planes_frag_pack(rb.data(), kp, C, cbl);
   std::vector<float> bias(2 * rows, 0.f);
   for (int i = 0; i < C; ++i) { bias[i] = h_ba[i]; bias[rows + i] = h_bb[i]; }
   half_t* dw = nullptr;
   float* db = nullptr;
-  HIP_TRYG(hipMalloc((void**)&dw, 2 * ra.size() * sizeof(half_t)));
+  HIP_TRYG(hipMalloc((void**)&dw, (fa.size() + fb.size()) * sizeof(half_t)));
   HIP_TRYG(hipMalloc((void**)&db, bias.size() * sizeof(float)));
-  HIP_TRYG(hipMemcpy(dw, ra.data(), ra.size() * sizeof(half_t), hipMemcpyHostToDevice));
-  HIP_TRYG(hipMemcpy(dw + ra.size(), rb.data(), rb.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(dw, fa.data(), fa.size() * sizeof(half_t), hipMemcpyHostToDevice));
+  HIP_TRYG(hipMemcpy(dw + fa.size(), fb.data(), fb.size() * sizeof(half_t), hipMemcpyHostToDevice));
   HIP_TRYG(hipMemcpy(db, bias.data(), bias.size() * sizeof(float), hipMemcpyHostToDevice));
   PlanesArgs a{};
   a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * ldx; a.ldx = ldx; a.H = H; a.W = W; a.B = B; a.Cin = C; a.Cout = C;
-  a.wa = dw; a.wb = dw + ra.size(); a.kpad_a = a.kpad_b = kp; a.rows_a = a.rows_b = rows;
+  a.wfa = dw; a.wfb = dw + fa.size(); a.cblocks_a = a.cblocks_b = cbl;
   a.ba = db; a.bb = db + rows;
   a.y = (half_t*)d_y; a.y_bstride = (long)H * W * ldy; a.ldy = ldy; a.act = 1;
   if (shortcut) { a.res = a.x; a.r_bstride = a.x_bstride; a.ldr = ldx; }
