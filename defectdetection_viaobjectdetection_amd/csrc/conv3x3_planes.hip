@@ -34,6 +34,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <utility>
 
 #include "common.h"
 
@@ -65,128 +66,170 @@ struct PCfg {
   static constexpr bool PAIR = PAIR_;
   static constexpr int NB1 = WP * NPB1, NB2 = WP * NPB2;
   static constexpr int NPB = NPB1 > NPB2 ? NPB1 : NPB2;
-  static constexpr int PIT = 6 * PPS;             // input pieces per wave and plane (issued in steps 0 .. 5)
+  static constexpr int PIT = 6 * PPS;             // input pieces per wave and plane
+  static constexpr int KSTEP = 2048 * WP;         // LDS bytes between consecutive pixel blocks of one wave
   static_assert(WC == 2 || WC == 4, "channel blocks per block");
 };
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>) (the 126 .. 162 MFMA slots of a phase; #pragma
+// unroll refuses a loop of that size with a barrier in one iteration)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+constexpr int FQ = 9;   // B fragment FIFO (registers): 18 fragments per pixel block, so every phase starts at slot 0
+constexpr int FD = 8;   // fragments in flight (an LDS read returns within eight MFMAs also when all four waves stream)
 
 template <class C>
 struct PState {
   float16v acc[C::NPB];
-  half8 wa[3][2];             // weight fragments (MFMA A operands) of three consecutive steps, straight from global memory
-  half8 fb[2][C::NPB];
+  half8 A[18];                // the phase's weight fragments (MFMA A operands): (tap, slice) -> 2 * tap + slice
+  half8 bq[FQ];
   int tb[9];                  // B fragment: LDS byte offset inside a plane for (tap, slice 0), pixel block 0 of this wave
   int pvoff[C::PIT];          // per-lane source offsets of the input pieces of the slab the loader is on
   __amdgpu_buffer_rsrc_t rs_x;
   char* smem;
   int wave, lane16;
-  int pcur, pnext;            // LDS byte offset of the current / the next phase's plane
-  // weight cursor: the fragments step g loads = those of step g + 2.  A convolution's fragments of one channel block are
-  // contiguous in K-loop order (plane, tap, slice): the cursor is a byte offset that advances by 2 KiB per step.
-  // weight stream: the fragments step g loads are those of step g + 2.  A convolution's fragments of one channel block are
-  // contiguous in K-loop order (plane, tap, slice), 2 KiB per step: steps 0 .. 6 of a phase load at wp_cur + 2 KiB * (tap + 2),
-  // steps 7, 8 the first two steps of the NEXT phase (wp_next: next plane, next convolution or next tile) -- both set per phase.
-  const char *wp_cur, *wp_next;
-  int wblock;                 // bytes of one channel block's fragments of one convolution (2 KiB * 9 * planes)
-  // input pieces of the phase: this wave issues piece m (LDS KiB wave + 4 m of the target slot) in step m / PPS; pieces from
-  // nreal on are zero fills of the spare KiB (a phase that streams nothing: nreal = 0)
+  int pcur, pnext;            // LDS byte offset of this / the next phase's plane
+  __amdgpu_buffer_rsrc_t rs_wn;   // the NEXT phase's 18 fragments (next plane, next convolution, next tile): 1 KiB each, lane-linear.
+                              // A descriptor per phase (scalar registers) + lane offset + constant: 64-bit per-lane addresses of
+                              // 18 fragments were 36 VGPRs -- spilled, and every scratch reload drains the memory pipeline
+  // input pieces of the phase: this wave issues piece m into LDS KiB wave + 4 m of the target slot; pieces from nreal on are
+  // zero fills of the spare KiB (a phase that streams nothing: nreal = 0)
   int nreal, px_soff, px_dst; // px_dst: LDS byte offset of this wave's piece 0
   int off_s;
 };
 
-// fp16 rounding of an epilogue value, opaque to mul + cvt fusion like m355_to_half, but not volatile: the sixteen values of a
-// pixel block are independent chains the scheduler may interleave (the volatile form cost 210 s_nops per transition)
+// fp16 rounding of an epilogue value, opaque to mul + cvt fusion like m355_to_half, but not volatile: independent chains stay
+// free to be interleaved
 __device__ __forceinline__ half_t to_half_rn(float v) {
   asm("" : "+v"(v));
   return (half_t)v;
 }
 
-// One K step: tap TAP of the current phase.  Entering: st.wa[TAP % 3] holds (or is about to receive) this step's two weight
-// fragments, st.wa[(TAP + 1) % 3] the next step's (in flight), fragment set 0 of fb holds K slice 0 of this step.
-// Straight-line code (no branch: the input pieces of a phase that streams nothing go to the spare KiB with out-of-range
-// offsets, i.e. as zero fills), so that the MFMAs, the LDS reads and the vector-memory issues of a step are ONE scheduling
-// region and the sched_group_barriers below can pin  MFMA, ds_read, (vmem)  triples: with one wave per SIMD every
-// instruction that is not issued beside an executing MFMA is matrix-pipe idle time.
-template <class C, int NPBC, int TAP>
-__device__ __forceinline__ void planes_step(PState<C>& st, int wc) {
-  constexpr int NT = (TAP + 1) % 9, CUR = TAP % 3, LD = (TAP + 2) % 3;
-  constexpr int NPC = TAP < 6 ? C::PPS : 0;             // input pieces of this step
-  static_assert(NPBC >= 3 + NPC, "pixel blocks per wave");
-  // weight fragments of step g + 2 (always issued: past the block's last step the pointers keep walking valid memory)
-  const char* const wsrc = (TAP < 7 ? st.wp_cur + (TAP + 2) * 2048 : st.wp_next + (TAP - 7) * 2048) + st.lane16;
-  // K slice 0: MFMAs interleaved with the reads of slice 1, the two weight loads and the input pieces
-  const int b1 = st.pcur + (st.tb[TAP] ^ 32);
+// The VALU work behind a finished pixel block, as a software pipeline over the MFMA slots of the phase (one wave per SIMD: a
+// dependent chain  mul -> exp -> add -> rcp -> mul  issued in one piece waits for every result; issued one stage per slot, six
+// independent instructions sit beside each MFMA).  Value c (0 .. 15) of block kk enters the pipe in slot 18 (kk + 1) + 1 + c --
+// block kk's last MFMA was issued two slots earlier -- and advances one stage per slot:
+//   +0 t = x * -log2(e)   +1 t = exp2(t)   +2 t = 1 + t   +3 t = rcp(t)   +4 y = x * t     (the five instructions of m355_silu)
+//   mode 2: +5 y += residual
+//   then (odd c) the pair (c - 1, c) is rounded to fp16, and behind c = 7 / 15 the eight values are stored:
+//   mode 1: into the hidden plane in LDS (the transition of a Bottleneck), mode 2: to the output tensor.
+template <int NPBC>
+struct PostPipe {
+  float t[8];            // running temporaries, by c % 8
+  float y[16];           // finished values of the block in flight (packed two slots after the second of a pair)
+  half8 o[2];            // the two 16-byte halves of a pixel's 16 channels
+};
+template <int NPBC, int n, int OFF>
+struct PipeAt {   // which value is at stage offset OFF in slot n
+  static constexpr int m = n - 1 - OFF;
+  static constexpr bool on = m >= 18 && (m % 18) < 16 && (m / 18 - 1) < NPBC;
+  static constexpr int kk = on ? m / 18 - 1 : 0, c = on ? m % 18 : 0;
+};
+
+template <class C, int NPBC, int MODE, int n, class Store>
+__device__ __forceinline__ void post_slot(PState<C>& st, PostPipe<NPBC>& pp, const half8 (&rv)[C::NPB2][2], bool has_res, Store&& store) {
+#pragma clang fp contract(off)
+  using A = PipeAt<NPBC, n, 0>;
+  using B = PipeAt<NPBC, n, 1>;
+  using Cc = PipeAt<NPBC, n, 2>;
+  using D = PipeAt<NPBC, n, 3>;
+  using E = PipeAt<NPBC, n, 4>;
+  using F = PipeAt<NPBC, n, 5>;
+  constexpr int PKO = MODE == 2 ? 6 : 5;
+  using P = PipeAt<NPBC, n, PKO>;
+  using W = PipeAt<NPBC, n, PKO + 1>;
+  if constexpr (A::on) pp.t[A::c % 8] = st.acc[A::kk][A::c] * -1.4426950408889634f;
+  if constexpr (B::on) pp.t[B::c % 8] = __builtin_amdgcn_exp2f(pp.t[B::c % 8]);
+  if constexpr (Cc::on) pp.t[Cc::c % 8] = 1.0f + pp.t[Cc::c % 8];
+  if constexpr (D::on) pp.t[D::c % 8] = __builtin_amdgcn_rcpf(pp.t[D::c % 8]);
+  if constexpr (E::on) pp.y[E::c] = st.acc[E::kk][E::c] * pp.t[E::c % 8];
+  if constexpr (MODE == 2 && F::on) {
+    if (has_res) pp.y[F::c] = pp.y[F::c] + (float)rv[F::kk][F::c / 8][F::c % 8];
+  }
+  if constexpr (P::on && (P::c & 1)) {
+    pp.o[P::c / 8][(P::c % 8) - 1] = to_half_rn(pp.y[P::c - 1]);
+    pp.o[P::c / 8][P::c % 8] = to_half_rn(pp.y[P::c]);
+  }
+  if constexpr (W::on && (W::c % 8) == 7) store(W::kk, W::c / 8, pp.o[W::c / 8]);
+}
+
+// One PHASE of a convolution: one input plane (32 channels) x nine taps for every pixel block of the wave, PIXEL-BLOCK MAJOR:
+// the 18 weight fragments of the phase sit in registers (loaded during the previous phase), block k runs its 18 MFMAs on one
+// accumulator back to back (a single accumulation chain of v_mfma_f32_32x32x16 issues at full rate), then block k + 1.  So the
+// LAST phase of a convolution finishes its pixel blocks one after the other and the VALU work behind a finished block runs
+// beside the MFMAs of the next one (PostPipe) instead of after the whole K loop -- it was 25 % of the kernel.
+// Every slot = one MFMA + one LDS read (+ a vector-memory issue, + the pipe's six VALU instructions), pinned by a sched_barrier.
+//   FIRST  first phase of the convolution: block k's first MFMA takes the bias vector as its C operand (no zero fill, no bias add)
+//   MODE   0 plain phase; 1 / 2: last phase with the post pipe; the caller handles what follows (no barrier here)
+//   PRIMED the previous phase already issued this phase's first FD fragment reads (after its barrier)
+template <class C, int NPBC, bool FIRST, int MODE, bool PRIMED, class Store>
+__device__ __forceinline__ void planes_phase(PState<C>& st, const float16v& bv, const half8 (&rv)[C::NPB2][2], bool has_res, Store&& store) {
+  constexpr int N = NPBC * 18;
+  constexpr int PSTEP = 3;                                       // slots between two input pieces
+  int addr[18];
 #pragma unroll
-  for (int k = 0; k < NPBC; ++k) {
-    st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.wa[CUR][0], st.fb[0][k], st.acc[k], 0, 0, 0);
-    st.fb[1][k] = *(const half8*)(st.smem + b1 + k * (2048 * C::WP));
-    if (k == 0) st.wa[LD][0] = *(const half8*)wsrc;
-    if (k == 1) st.wa[LD][1] = *(const half8*)(wsrc + 1024);
-    if (k >= 2 && k < 2 + NPC) {
-      const int m = TAP * C::PPS + (k - 2);
+  for (int t = 0; t < 9; ++t) {
+    addr[2 * t] = st.pcur + st.tb[t];
+    addr[2 * t + 1] = addr[2 * t] ^ 32;
+  }
+  PostPipe<NPBC> pp;
+  if (!PRIMED) {
+#pragma unroll
+    for (int n = 0; n < FD; ++n) st.bq[n % FQ] = *(const half8*)(st.smem + addr[n % 18] + (n / 18) * C::KSTEP);
+  }
+  static_for<N>([&](auto nc) __attribute__((always_inline)) {
+    constexpr int n = decltype(nc)::value;
+    constexpr int k = n / 18, i = n % 18;
+    if constexpr (MODE == 0 && n == N - FD) {
+      // every read of this plane has been issued.  Phase end: this wave's pieces of the next plane and the next phase's weight
+      // fragments have landed, then every wave's; the next phase's first reads go out under this phase's last MFMAs
+      // (younger than the pieces: exactly the 18 - FD weight loads of the last block's first slots, which may stay in flight)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(18 - FD) : "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if constexpr (FIRST && i == 0)
+      st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.A[i], st.bq[n % FQ], bv, 0, 0, 0);
+    else
+      st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.A[i], st.bq[n % FQ], st.acc[k], 0, 0, 0);
+    if constexpr (n + FD < N) {
+      constexpr int m = n + FD;
+      st.bq[m % FQ] = *(const half8*)(st.smem + addr[m % 18] + (m / 18) * C::KSTEP);
+    } else if constexpr (MODE == 0) {
+      constexpr int m = n + FD - N;   // the next phase's fragment m (its block 0)
+      st.bq[m % FQ] = *(const half8*)(st.smem + st.pnext + (st.tb[m / 2] ^ ((m & 1) << 5)));
+    }
+    // the next phase's weight fragments: fragment i is reloaded right behind its last MFMA of this phase (the last pixel block), 18
+    // slots + the barrier before its first MFMA of the next phase: an L2 hit (every CU streams the same fragments).  One set of
+    // 18 fragments in registers, ONE code body for every middle phase of a convolution (it stays in the instruction cache).
+    if constexpr (k == NPBC - 1) {
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const u4 wv = __builtin_amdgcn_raw_buffer_load_b128(st.rs_wn, st.lane16, i * 1024, 0);
+      st.A[i] = __builtin_bit_cast(half8, wv);
+    }
+    // the input pieces of the phase's target plane, early in the phase
+    if constexpr (n >= 1 && (n - 1) % PSTEP == 0 && (n - 1) / PSTEP < C::PIT) {
+      constexpr int m = (n - 1) / PSTEP;
       const bool real = m < st.nreal;
       dma16(st.rs_x, real ? st.pvoff[m] : (int)0x80000000, st.px_soff, st.smem + (real ? st.px_dst + m * 4096 : st.off_s));
     }
-  }
-#pragma unroll
-  for (int k = 0; k < NPBC; ++k) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // 1 DS read
-    if (k < 2 + NPC) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // 1 VMEM read
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  if (TAP == 8) {
-    // phase end: this wave's pieces of the next plane have landed (issued in steps 0 .. 5; younger: the six weight loads of steps
-    // 6, 7, 8), then every wave's
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (MODE != 0) post_slot<C, NPBC, MODE, n>(st, pp, rv, has_res, store);
     __builtin_amdgcn_sched_barrier(0);
+  });
+  if constexpr (MODE != 0) {   // drain: the last block's values
+    static_for<16 + 8>([&](auto nc) __attribute__((always_inline)) {
+      constexpr int n = N + decltype(nc)::value;
+      post_slot<C, NPBC, MODE, n>(st, pp, rv, has_res, store);
+      __builtin_amdgcn_sched_barrier(0);
+    });
   }
-  // K slice 1: MFMAs interleaved with the reads of the next step's slice 0
-  const int b0 = (TAP < 8 ? st.pcur : st.pnext) + st.tb[NT];
-#pragma unroll
-  for (int k = 0; k < NPBC; ++k) {
-    st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.wa[CUR][1], st.fb[1][k], st.acc[k], 0, 0, 0);
-    st.fb[0][k] = *(const half8*)(st.smem + b0 + k * (2048 * C::WP));
-  }
-#pragma unroll
-  for (int k = 0; k < NPBC; ++k) {
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
-    __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-}
-
-// SiLU of eight values, the five instructions of m355_silu (x * rcp(1 + exp2(-log2e * x)): the same bits) issued as five rows
-// of eight independent instructions.  The compiler schedules the 16 chains of a pixel block one after the other through one
-// temporary (register pressure heuristics at 256 VGPRs): every instruction then waits for its predecessor's result and each
-// transcendental needs an s_nop before its use -- 54 cycles per value measured; interleaved it is the issue cost, 28.
-__device__ __forceinline__ void silu8(float (&v)[8]) {
-  float t[8];
-  asm("v_mul_f32 %8, 0xbfb8aa3b, %0\n\tv_mul_f32 %9, 0xbfb8aa3b, %1\n\tv_mul_f32 %10, 0xbfb8aa3b, %2\n\tv_mul_f32 %11, 0xbfb8aa3b, %3\n\t"
-      "v_mul_f32 %12, 0xbfb8aa3b, %4\n\tv_mul_f32 %13, 0xbfb8aa3b, %5\n\tv_mul_f32 %14, 0xbfb8aa3b, %6\n\tv_mul_f32 %15, 0xbfb8aa3b, %7\n\t"
-      "v_exp_f32 %8, %8\n\tv_exp_f32 %9, %9\n\tv_exp_f32 %10, %10\n\tv_exp_f32 %11, %11\n\t"
-      "v_exp_f32 %12, %12\n\tv_exp_f32 %13, %13\n\tv_exp_f32 %14, %14\n\tv_exp_f32 %15, %15\n\t"
-      "v_add_f32 %8, 1.0, %8\n\tv_add_f32 %9, 1.0, %9\n\tv_add_f32 %10, 1.0, %10\n\tv_add_f32 %11, 1.0, %11\n\t"
-      "v_add_f32 %12, 1.0, %12\n\tv_add_f32 %13, 1.0, %13\n\tv_add_f32 %14, 1.0, %14\n\tv_add_f32 %15, 1.0, %15\n\t"
-      "v_rcp_f32 %8, %8\n\tv_rcp_f32 %9, %9\n\tv_rcp_f32 %10, %10\n\tv_rcp_f32 %11, %11\n\t"
-      "v_rcp_f32 %12, %12\n\tv_rcp_f32 %13, %13\n\tv_rcp_f32 %14, %14\n\tv_rcp_f32 %15, %15\n\t"
-      "v_mul_f32 %0, %0, %8\n\tv_mul_f32 %1, %1, %9\n\tv_mul_f32 %2, %2, %10\n\tv_mul_f32 %3, %3, %11\n\t"
-      "v_mul_f32 %4, %4, %12\n\tv_mul_f32 %5, %5, %13\n\tv_mul_f32 %6, %6, %14\n\tv_mul_f32 %7, %7, %15"
-      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-        "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "=&v"(t[4]), "=&v"(t[5]), "=&v"(t[6]), "=&v"(t[7]));
-}
-
-template <class C, int NPBC>
-__device__ __forceinline__ void planes_phase(PState<C>& st, int wc) {
-  planes_step<C, NPBC, 0>(st, wc);
-  planes_step<C, NPBC, 1>(st, wc);
-  planes_step<C, NPBC, 2>(st, wc);
-  planes_step<C, NPBC, 3>(st, wc);
-  planes_step<C, NPBC, 4>(st, wc);
-  planes_step<C, NPBC, 5>(st, wc);
-  planes_step<C, NPBC, 6>(st, wc);
-  planes_step<C, NPBC, 7>(st, wc);
-  planes_step<C, NPBC, 8>(st, wc);
 }
 
 struct PTile {
@@ -226,7 +269,8 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   st.wave = wave;
   st.lane16 = lane * 16;
   st.off_s = g.off_s;
-  st.wblock = 2048 * 9 * g.NP;
+  const int pbytes = 18 * 1024;                          // fragments of one phase
+  const long wblock = (long)pbytes * g.NP;               // ... of one channel block of one convolution
   const int nreal_wave = (g.npieces - wave + 3) / 4;     // pieces of a plane this wave issues
   const int img_stride = (int)a.x_bstride * 2;
   st.rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((a.B - 1) * a.x_bstride + (long)H * W * a.ldx) * 2, 0x00020000);
@@ -266,31 +310,28 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
     }
     return bv;
   };
+  auto load_frags = [&](const char* src, half8 (&dst)[18]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 18; ++j) dst[j] = *(const half8*)(src + st.lane16 + j * 1024);
+  };
 
   // ---- the block's stream of tiles
   int vb = blockIdx.x;
   PTile cur = decode(vb), nxt = cur;
   bool more = vb + nwg < ntiles;
   if (more) nxt = decode(vb + nwg);
-  const char* const wbase_a = C::PAIR ? (const char*)a.wfa + (long)wc * st.wblock : nullptr;   // pair: this wave's channel block in either conv
-  const char* wbase_b = (const char*)a.wfb + (long)(cur.ch / 32 + wc) * st.wblock;               // second / only conv, this tile
-  const char* wbase_b_next = (const char*)a.wfb + (long)(nxt.ch / 32 + wc) * st.wblock;          // ... the block's next tile
+  const char* const wbase_a = C::PAIR ? (const char*)a.wfa + wc * wblock : nullptr;   // pair: this wave's channel block in the first conv
+  const char* wbase_b = (const char*)a.wfb + (cur.ch / 32 + wc) * wblock;             // second / only conv, this tile
+  const char* wbase_b_next = (const char*)a.wfb + (nxt.ch / 32 + wc) * wblock;        // ... the block's next tile
 
-  // ---- prologue: input plane 0 into slot 0, the weight fragments of steps 0 and 1
+  // ---- prologue: input plane 0 into slot 0, the weight fragments of the first phase
   piece_offsets(cur);
 #pragma unroll
   for (int m = 0; m < C::PIT; ++m) {
     const int k = wave + 4 * m;
     if (k < g.npieces) dma16(st.rs_x, st.pvoff[m], cur.b * img_stride, smem + g.off_x + k * 1024);
   }
-  {
-    const char* w0 = (C::PAIR ? wbase_a : wbase_b) + st.lane16;
-#pragma unroll
-    for (int sgi = 0; sgi < 2; ++sgi) {
-      st.wa[sgi][0] = *(const half8*)(w0 + sgi * 2048);
-      st.wa[sgi][1] = *(const half8*)(w0 + sgi * 2048 + 1024);
-    }
-  }
+  load_frags(C::PAIR ? wbase_a : wbase_b, st.A);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (a.stamps) stamp[1] = __builtin_amdgcn_s_memtime();
@@ -298,99 +339,101 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   const int xslot = g.xrows * ROWB;   // bytes of an input ring slot
   const int iplane = g.irows * ROWB;  // bytes of an intermediate plane
   int xg = 0;                         // input planes consumed so far by this block (ring slot = xg & 1)
+  const int NP = g.NP;                // even
 
   while (true) {
     // =========================== first convolution (pair mode): R + 2 rows of the hidden tensor ===========================
     if constexpr (C::PAIR) {
       tap_offsets(-1);
-#pragma unroll
-      for (int k = 0; k < C::NPB1; ++k)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) st.acc[k][j] = 0.f;
-      // slice 0 of step 0 (plane 0 of the tile)
-      {
-        const int p0 = g.off_x + (xg & 1) * xslot;
-#pragma unroll
-        for (int k = 0; k < C::NPB1; ++k) st.fb[0][k] = *(const half8*)(smem + p0 + st.tb[0] + k * (2048 * C::WP));
-      }
-      for (int p = 0; p < g.NP; ++p) {
+      char* const plane = smem + wc * iplane;
+      // the transition: a finished half pixel (8 channels, fp16) goes into plane wc of the hidden tensor.  The zero padding of the
+      // second conv is written OVER it afterwards.
+      auto store1 = [&](int k, int hh, const half8& o) __attribute__((always_inline)) {
+        const int i = 32 * (wp + C::WP * k) + l31;
+        *(half8*)(plane + i * ROWB + (((2 * h + hh) ^ ((i >> 2) & 3)) << 4)) = o;
+      };
+      const half8 rv0[C::NPB2][2] = {};
+      const float16v bv = load_bias(a.ba, 0);
+      auto setup1 = [&](int p) __attribute__((always_inline)) {
         st.pcur = g.off_x + (xg & 1) * xslot;
-        st.pnext = p + 1 < g.NP ? g.off_x + ((xg + 1) & 1) * xslot : st.pcur;
-        st.nreal = p + 1 < g.NP ? nreal_wave : 0;   // stream plane p + 1 of this tile into the other slot
+        st.pnext = g.off_x + ((xg + 1) & 1) * xslot;
+        st.nreal = p + 1 < NP ? nreal_wave : 0;   // stream plane p + 1 of this tile into the other slot
         st.px_soff = cur.b * img_stride + (p + 1) * 64;
-        st.px_dst = g.off_x + ((xg + 1) & 1) * xslot + wave * 1024;
-        st.wp_cur = wbase_a + p * (9 * 2048);
-        st.wp_next = p + 1 < g.NP ? st.wp_cur + 9 * 2048 : wbase_b;
-        planes_phase<C, C::NPB1>(st, wc);
+        st.px_dst = st.pnext + wave * 1024;
+        st.rs_wn = __builtin_amdgcn_make_buffer_rsrc((void*)(p + 1 < NP ? wbase_a + (p + 1) * pbytes : wbase_b), 0, pbytes, 0x00020000);
         ++xg;
+      };
+      setup1(0);
+      planes_phase<C, C::NPB1, true, 0, false>(st, bv, rv0, false, store1);
+      for (int p = 1; p + 1 < NP; ++p) {
+        setup1(p);
+        planes_phase<C, C::NPB1, false, 0, true>(st, bv, rv0, false, store1);
       }
+      setup1(NP - 1);
       if (a.stamps) stamp[2] = __builtin_amdgcn_s_memtime();
-      // ---- transition: bias, SiLU, fp16 into plane wc of the hidden tensor; then the zero padding of the second conv is
-      // written OVER it (the shared pad column ci = 0 of every row, the rows outside the image): no per-value select
+      planes_phase<C, C::NPB1, false, 1, true>(st, bv, rv0, false, store1);
       if (more) piece_offsets(nxt);   // every piece of this tile has been issued: the loader moves on
-      {
-        const float16v bv = load_bias(a.ba, 0);
-        char* const plane = smem + wc * iplane;
-#pragma unroll
-        for (int k = 0; k < C::NPB1; ++k) {
-          const int i = 32 * (wp + C::WP * k) + l31;
-          half8 o[2];
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = st.acc[k][hh * 8 + j] + bv[hh * 8 + j];
-            silu8(v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[hh][j] = (half_t)v[j];
-          }
-          char* rowp = plane + i * ROWB;
-          const int sw = (i >> 2) & 3;
-          *(half8*)(rowp + (((2 * h) ^ sw) << 4)) = o[0];
-          *(half8*)(rowp + (((2 * h + 1) ^ sw) << 4)) = o[1];
-          __builtin_amdgcn_sched_barrier(0);   // one pixel block at a time: 16 accumulator values in VGPRs, not 144
-        }
-        // zero padding (this wave's writes are ordered: LDS operations of one wave complete in order).  Only the wp == 0 wave of a
-        // channel block does it -- after a barrier when a second pixel group wrote parts of the plane.
-        if (C::WP > 1) {
-          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-        }
-        if (wp == 0) {
-          const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-          // pad column: rows ri * PW, ri = 0 .. R + 2 (the last one is the pad behind the last row); 4 lanes x 16 bytes each
-          for (int e = lane; e < 4 * (R + 3); e += 64) *(half8*)(plane + (e >> 2) * PW * ROWB + ((e & 3) << 4)) = z;
-          // rows outside the image: only the first and the last slab of an image have any
+      // zero padding (a wave's LDS operations complete in order).  Only the wp == 0 wave of a channel block writes it -- after
+      // a barrier when a second pixel group wrote parts of the plane.
+      if (C::WP > 1) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+      if (wp == 0) {
+        const half8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        // pad column: rows ri * PW, ri = 0 .. R + 2 (the last one is the pad behind the last row); 4 lanes x 16 bytes each
+        for (int e = lane; e < 4 * (R + 3); e += 64) *(half8*)(plane + (e >> 2) * PW * ROWB + ((e & 3) << 4)) = z;
+        // rows outside the image: only the first and the last slab of an image have any
 #pragma unroll 1
-          for (int ri = 0; ri < R + 2; ++ri) {
-            const int iy = cur.y0 - 1 + ri;
-            if ((unsigned)iy < (unsigned)H) continue;
-            for (int e = lane; e < 4 * PW; e += 64) *(half8*)(plane + (ri * PW + (e >> 2)) * ROWB + ((e & 3) << 4)) = z;
-          }
+        for (int ri = 0; ri < R + 2; ++ri) {
+          const int iy = cur.y0 - 1 + ri;
+          if ((unsigned)iy < (unsigned)H) continue;
+          for (int e = lane; e < 4 * PW; e += 64) *(half8*)(plane + (ri * PW + (e >> 2)) * ROWB + ((e & 3) << 4)) = z;
         }
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (a.stamps) stamp[3] = __builtin_amdgcn_s_memtime();
     }
     // =========================== second (or only) convolution: R rows ===========================
     {
       tap_offsets(0);
+      const int npl = C::PAIR ? g.NPo : NP;
+      // ---- epilogue state: pixel q -> (row, column) by an exact float division (q < 2^11); the residual of every block is loaded
+      // before the last phase starts
+      const float rpw = 1.0f / (float)PW;
+      const int c0 = cur.ch + wc * 32 + 16 * h;
+      const bool ch_ok = c0 + 16 <= a.Cout;
+      int off_y[C::NPB2];
+      half8 rv[C::NPB2][2];
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)cur.b * a.y_bstride), 0, (int)((long)H * W * a.ldy * 2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + (long)cur.b * a.r_bstride : a.x), 0, (int)((long)H * W * a.ldr * 2), 0x00020000);
+      auto prep2 = [&]() __attribute__((always_inline)) {
 #pragma unroll
-      for (int k = 0; k < C::NPB2; ++k)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) st.acc[k][j] = 0.f;
-      {
-        const int p0 = C::PAIR ? 0 : g.off_x + (xg & 1) * xslot;
-#pragma unroll
-        for (int k = 0; k < C::NPB2; ++k) st.fb[0][k] = *(const half8*)(smem + p0 + st.tb[0] + k * (2048 * C::WP));
-      }
-      const int npl = C::PAIR ? g.NPo : g.NP;
-      for (int p = 0; p < npl; ++p) {
+        for (int k = 0; k < C::NPB2; ++k) {
+          const int q = 32 * (wp + C::WP * k) + l31;
+          const int r = (int)(((float)q + 0.5f) * rpw), c = q - r * PW;
+          const int yy = cur.y0 + r;
+          const bool ok = c < W && r < R && yy < H && ch_ok;
+          const int pix = yy * W + c;
+          off_y[k] = ok ? (pix * a.ldy + c0) * 2 : (int)0x80000000;   // byte offset; out of range: the store is dropped
+          if (a.res) {   // (a pixel outside the image reads out of range: zeros)
+            const int ro = ok ? (pix * a.ldr + c0) * 2 : (int)0x80000000;
+            rv[k][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro, 0, 0));
+            rv[k][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro, 16, 0));
+          }
+        }
+      };
+      auto store2 = [&](int k, int hh, const half8& o) __attribute__((always_inline)) {
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rs_y, off_y[k], 16 * hh, 0);
+      };
+      const float16v bv2 = load_bias(a.bb, cur.ch);
+      auto setup2 = [&](int p) __attribute__((always_inline)) {
         bool pieces = false;
         if (C::PAIR) {
           st.pcur = p * iplane;
-          st.pnext = p + 1 < npl ? (p + 1) * iplane : st.pcur;
+          st.pnext = (p + 1) * iplane;
           if (p == 0 && more) {   // plane 0 of the next tile into the slot the next tile starts with
             pieces = true;
             st.px_soff = nxt.b * img_stride;
@@ -400,73 +443,29 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
           st.pcur = g.off_x + (xg & 1) * xslot;
           st.pnext = g.off_x + ((xg + 1) & 1) * xslot;
           st.px_dst = st.pnext + wave * 1024;
-          if (p + 1 < g.NP) {
+          if (p + 1 < NP) {
             pieces = true;
             st.px_soff = cur.b * img_stride + (p + 1) * 64;
           } else if (more) {
             piece_offsets(nxt);
             pieces = true;
             st.px_soff = nxt.b * img_stride;
-          } else {
-            st.pnext = st.pcur;
           }
           ++xg;
         }
         st.nreal = pieces ? nreal_wave : 0;
-        st.wp_cur = wbase_b + p * (9 * 2048);
-        st.wp_next = p + 1 < npl ? st.wp_cur + 9 * 2048 : (C::PAIR ? wbase_a : wbase_b_next);
-        planes_phase<C, C::NPB2>(st, wc);
+        st.rs_wn = __builtin_amdgcn_make_buffer_rsrc((void*)(p + 1 < npl ? wbase_b + (p + 1) * pbytes : (C::PAIR ? wbase_a : wbase_b_next)), 0, pbytes, 0x00020000);
+      };
+      setup2(0);
+      planes_phase<C, C::NPB2, true, 0, false>(st, bv2, rv, false, store2);
+      for (int p = 1; p + 1 < npl; ++p) {
+        setup2(p);
+        planes_phase<C, C::NPB2, false, 0, true>(st, bv2, rv, false, store2);
       }
+      setup2(npl - 1);
+      prep2();
       if (a.stamps) stamp[4] = __builtin_amdgcn_s_memtime();
-      // ---- epilogue: bias, SiLU, residual, fp16, two 16-byte stores per pixel.  Pixel q -> (row, column) by an exact float
-      // division (q < 2^11); every residual load is issued before the first value is touched.
-      {
-#pragma clang fp contract(off)
-        const float rpw = 1.0f / (float)PW;
-        const int c0 = cur.ch + wc * 32 + 16 * h;
-        const bool ch_ok = c0 + 16 <= a.Cout;
-        int off_y[C::NPB2], off_r[C::NPB2];
-        half8 rv[C::NPB2][2];
-#pragma unroll
-        for (int k = 0; k < C::NPB2; ++k) {
-          const int q = 32 * (wp + C::WP * k) + l31;
-          const int r = (int)(((float)q + 0.5f) * rpw), c = q - r * PW;
-          const int yy = cur.y0 + r;
-          const bool ok = c < W && r < R && yy < H && ch_ok;
-          const int pix = yy * W + c;
-          off_y[k] = ok ? pix * a.ldy + c0 : -1;
-          off_r[k] = pix * a.ldr + c0;
-          if (a.res && ok) {
-            const half_t* rp = a.res + (long)cur.b * a.r_bstride + off_r[k];
-            rv[k][0] = *(const half8*)rp;
-            rv[k][1] = *(const half8*)(rp + 8);
-          }
-        }
-        const float16v bv2 = load_bias(a.bb, cur.ch);
-        half_t* const yb = a.y + (long)cur.b * a.y_bstride;
-#pragma unroll
-        for (int k = 0; k < C::NPB2; ++k) {
-          half8 o[2];
-#pragma unroll
-          for (int hh = 0; hh < 2; ++hh) {
-            float v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = st.acc[k][hh * 8 + j] + bv2[hh * 8 + j];
-            silu8(v);
-            if (a.res) {
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] += (float)rv[k][hh][j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[hh][j] = to_half_rn(v[j]);
-          }
-          if (off_y[k] >= 0) {
-            *(half8*)(yb + off_y[k]) = o[0];
-            *(half8*)(yb + off_y[k] + 8) = o[1];
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
+      planes_phase<C, C::NPB2, false, 2, true>(st, bv2, rv, a.res != nullptr, store2);
     }
     if (!more) break;
     vb += nwg;
@@ -474,9 +473,11 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
     more = vb + nwg < ntiles;
     if (more) nxt = decode(vb + nwg);
     wbase_b = wbase_b_next;
-    wbase_b_next = (const char*)a.wfb + (long)(nxt.ch / 32 + wc) * st.wblock;
-    // (the next tile's first phases end in barriers before anything of this tile's LDS state is overwritten: input slots
-    // alternate, the hidden planes are rewritten only in the next transition)
+    wbase_b_next = (const char*)a.wfb + (nxt.ch / 32 + wc) * wblock;
+    // this tile's last phase ended without a barrier: the next tile's plane 0 (pieces issued in an earlier phase of this tile by
+    // every wave) and its first weight fragments must have landed before anyone reads them
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
   }
   if (a.stamps && lane == 0) {
     stamp[5] = __builtin_amdgcn_s_memtime();
