@@ -117,7 +117,7 @@ __device__ __forceinline__ half_t to_half_rn(float v) {
 // independent instructions sit beside each MFMA).  Value c (0 .. 15) of block kk enters the pipe in slot 18 (kk + 1) + 1 + c --
 // block kk's last MFMA was issued two slots earlier -- and advances one stage per slot:
 //   +0 t = x * -log2(e)   +1 t = exp2(t)   +2 t = 1 + t   +3 t = rcp(t)   +4 y = x * t     (the five instructions of m355_silu)
-//   mode 2: +5 y += residual
+//   modes 2 / 3 (output conv without / with a residual): +5 y += residual
 //   then (odd c) the pair (c - 1, c) is rounded to fp16, and behind c = 7 / 15 the eight values are stored:
 //   mode 1: into the hidden plane in LDS (the transition of a Bottleneck), mode 2: to the output tensor.
 template <int NPBC>
@@ -125,6 +125,7 @@ struct PostPipe {
   float t[8];            // running temporaries, by c % 8
   float y[16];           // finished values of the block in flight (packed two slots after the second of a pair)
   half8 o[2];            // the two 16-byte halves of a pixel's 16 channels
+  half8 rv[2][2];        // mode 3: the residual of the block in the pipe / of the next one (loaded one block ahead, an L2 hit)
 };
 template <int NPBC, int n, int OFF>
 struct PipeAt {   // which value is at stage offset OFF in slot n
@@ -134,7 +135,7 @@ struct PipeAt {   // which value is at stage offset OFF in slot n
 };
 
 template <class C, int NPBC, int MODE, int n, class Store>
-__device__ __forceinline__ void post_slot(PState<C>& st, PostPipe<NPBC>& pp, const half8 (&rv)[C::NPB2][2], bool has_res, Store&& store) {
+__device__ __forceinline__ void post_slot(PState<C>& st, PostPipe<NPBC>& pp, Store&& store) {
 #pragma clang fp contract(off)
   using A = PipeAt<NPBC, n, 0>;
   using B = PipeAt<NPBC, n, 1>;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void post_slot(PState<C>& st, PostPipe<NPBC>& pp, con
   using D = PipeAt<NPBC, n, 3>;
   using E = PipeAt<NPBC, n, 4>;
   using F = PipeAt<NPBC, n, 5>;
-  constexpr int PKO = MODE == 2 ? 6 : 5;
+  constexpr int PKO = MODE == 3 ? 6 : 5;
   using P = PipeAt<NPBC, n, PKO>;
   using W = PipeAt<NPBC, n, PKO + 1>;
   if constexpr (A::on) pp.t[A::c % 8] = st.acc[A::kk][A::c] * -1.4426950408889634f;
@@ -150,14 +151,12 @@ __device__ __forceinline__ void post_slot(PState<C>& st, PostPipe<NPBC>& pp, con
   if constexpr (Cc::on) pp.t[Cc::c % 8] = 1.0f + pp.t[Cc::c % 8];
   if constexpr (D::on) pp.t[D::c % 8] = __builtin_amdgcn_rcpf(pp.t[D::c % 8]);
   if constexpr (E::on) pp.y[E::c] = st.acc[E::kk][E::c] * pp.t[E::c % 8];
-  if constexpr (MODE == 2 && F::on) {
-    if (has_res) pp.y[F::c] = pp.y[F::c] + (float)rv[F::kk][F::c / 8][F::c % 8];
-  }
+  if constexpr (MODE == 3 && F::on) pp.y[F::c] = __builtin_fmaf((float)pp.rv[F::kk & 1][F::c / 8][F::c % 8], 1.0f, pp.y[F::c]);   // = y + residual, one v_fma_mix
   if constexpr (P::on && (P::c & 1)) {
     pp.o[P::c / 8][(P::c % 8) - 1] = to_half_rn(pp.y[P::c - 1]);
     pp.o[P::c / 8][P::c % 8] = to_half_rn(pp.y[P::c]);
   }
-  if constexpr (W::on && (W::c % 8) == 7) store(W::kk, W::c / 8, pp.o[W::c / 8]);
+  if constexpr (W::on && (W::c % 8) == 7) store.put(W::kk, W::c / 8, pp.o[W::c / 8]);
 }
 
 // One PHASE of a convolution: one input plane (32 channels) x nine taps for every pixel block of the wave, PIXEL-BLOCK MAJOR:
@@ -167,10 +166,11 @@ __device__ __forceinline__ void post_slot(PState<C>& st, PostPipe<NPBC>& pp, con
 // beside the MFMAs of the next one (PostPipe) instead of after the whole K loop -- it was 25 % of the kernel.
 // Every slot = one MFMA + one LDS read (+ a vector-memory issue, + the pipe's six VALU instructions), pinned by a sched_barrier.
 //   FIRST  first phase of the convolution: block k's first MFMA takes the bias vector as its C operand (no zero fill, no bias add)
-//   MODE   0 plain phase; 1 / 2: last phase with the post pipe; the caller handles what follows (no barrier here)
+//   MODE   0 plain phase; 1 / 2 / 3: last phase with the post pipe (transition / output / output + residual); the caller handles
+//          what follows (no barrier here)
 //   PRIMED the previous phase already issued this phase's first FD fragment reads (after its barrier)
 template <class C, int NPBC, bool FIRST, int MODE, bool PRIMED, class Store>
-__device__ __forceinline__ void planes_phase(PState<C>& st, const float16v& bv, const half8 (&rv)[C::NPB2][2], bool has_res, Store&& store) {
+__device__ __forceinline__ void planes_phase(PState<C>& st, const float16v& bv, Store&& store) {
   constexpr int N = NPBC * 18;
   constexpr int PSTEP = 3;                                       // slots between two input pieces
   int addr[18];
@@ -220,13 +220,15 @@ __device__ __forceinline__ void planes_phase(PState<C>& st, const float16v& bv, 
       const bool real = m < st.nreal;
       dma16(st.rs_x, real ? st.pvoff[m] : (int)0x80000000, st.px_soff, st.smem + (real ? st.px_dst + m * 4096 : st.off_s));
     }
-    if constexpr (MODE != 0) post_slot<C, NPBC, MODE, n>(st, pp, rv, has_res, store);
+    // block k's residual: first used in slot 18 (k + 1) + 6; the buffer's previous tenant (block k - 2) was last read in slot 18 k + 3
+    if constexpr (MODE == 3 && i == 5) store.load_res(k, pp.rv[k & 1]);
+    if constexpr (MODE != 0) post_slot<C, NPBC, MODE, n>(st, pp, store);
     __builtin_amdgcn_sched_barrier(0);
   });
   if constexpr (MODE != 0) {   // drain: the last block's values
     static_for<16 + 8>([&](auto nc) __attribute__((always_inline)) {
       constexpr int n = N + decltype(nc)::value;
-      post_slot<C, NPBC, MODE, n>(st, pp, rv, has_res, store);
+      post_slot<C, NPBC, MODE, n>(st, pp, store);
       __builtin_amdgcn_sched_barrier(0);
     });
   }
@@ -236,7 +238,7 @@ struct PTile {
   int b, y0, ch;   // image, first output row, first output channel
 };
 
-template <class C>
+template <class C, bool RES>
 __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, const PlanesGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   const int H = a.H, W = a.W, PW = g.PW, R = g.R;
   const int nwg = gridDim.x, ntiles = g.ntiles;
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic: start of phase 0, 1, 2, last of either conv, end
   if (a.stamps) stamp[0] = __builtin_amdgcn_s_memtime();
 
   // XCD-aware persistent walk (as conv3x3_m32.hip): the virtual blocks of one XCD cover a contiguous run of tiles; channel
@@ -348,11 +351,14 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
       char* const plane = smem + wc * iplane;
       // the transition: a finished half pixel (8 channels, fp16) goes into plane wc of the hidden tensor.  The zero padding of the
       // second conv is written OVER it afterwards.
-      auto store1 = [&](int k, int hh, const half8& o) __attribute__((always_inline)) {
-        const int i = 32 * (wp + C::WP * k) + l31;
-        *(half8*)(plane + i * ROWB + (((2 * h + hh) ^ ((i >> 2) & 3)) << 4)) = o;
-      };
-      const half8 rv0[C::NPB2][2] = {};
+      struct Store1 {
+        char* plane; int wp, l31, h;
+        __device__ __forceinline__ void put(int k, int hh, const half8& o) const {
+          const int i = 32 * (wp + C::WP * k) + l31;
+          *(half8*)(plane + i * ROWB + (((2 * h + hh) ^ ((i >> 2) & 3)) << 4)) = o;
+        }
+        __device__ __forceinline__ void load_res(int, half8 (&)[2]) const {}
+      } store1{plane, wp, l31, h};
       const float16v bv = load_bias(a.ba, 0);
       auto setup1 = [&](int p) __attribute__((always_inline)) {
         st.pcur = g.off_x + (xg & 1) * xslot;
@@ -364,14 +370,16 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
         ++xg;
       };
       setup1(0);
-      planes_phase<C, C::NPB1, true, 0, false>(st, bv, rv0, false, store1);
+      if (a.stamps) pst[0] = __builtin_amdgcn_s_memtime();
+      planes_phase<C, C::NPB1, true, 0, false>(st, bv, store1);
       for (int p = 1; p + 1 < NP; ++p) {
         setup1(p);
-        planes_phase<C, C::NPB1, false, 0, true>(st, bv, rv0, false, store1);
+        if (a.stamps && p < 3) pst[p] = __builtin_amdgcn_s_memtime();
+        planes_phase<C, C::NPB1, false, 0, true>(st, bv, store1);
       }
       setup1(NP - 1);
-      if (a.stamps) stamp[2] = __builtin_amdgcn_s_memtime();
-      planes_phase<C, C::NPB1, false, 1, true>(st, bv, rv0, false, store1);
+      if (a.stamps) stamp[2] = pst[3] = __builtin_amdgcn_s_memtime();
+      planes_phase<C, C::NPB1, false, 1, true>(st, bv, store1);
       if (more) piece_offsets(nxt);   // every piece of this tile has been issued: the loader moves on
       // zero padding (a wave's LDS operations complete in order).  Only the wp == 0 wave of a channel block writes it -- after
       // a barrier when a second pixel group wrote parts of the plane.
@@ -399,35 +407,34 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
     {
       tap_offsets(0);
       const int npl = C::PAIR ? g.NPo : NP;
-      // ---- epilogue state: pixel q -> (row, column) by an exact float division (q < 2^11); the residual of every block is loaded
-      // before the last phase starts
-      const float rpw = 1.0f / (float)PW;
-      const int c0 = cur.ch + wc * 32 + 16 * h;
-      const bool ch_ok = c0 + 16 <= a.Cout;
-      int off_y[C::NPB2];
-      half8 rv[C::NPB2][2];
-      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-      const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)cur.b * a.y_bstride), 0, (int)((long)H * W * a.ldy * 2), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void*)(a.res ? a.res + (long)cur.b * a.r_bstride : a.x), 0, (int)((long)H * W * a.ldr * 2), 0x00020000);
-      auto prep2 = [&]() __attribute__((always_inline)) {
-#pragma unroll
-        for (int k = 0; k < C::NPB2; ++k) {
+      // ---- epilogue: pixel q -> (row, column) by an exact float division (q < 2^11) when a block's values are stored / its residual
+      // is fetched (one block ahead of its use); out-of-image pixels get an out-of-range buffer offset: zeros / dropped stores
+      struct Store2 {
+        __amdgpu_buffer_rsrc_t rs_y, rs_r;
+        int wp, l31, PW, W, R, H, y0, ldy, ldr, c0; bool ch_ok; float rpw;
+        __device__ __forceinline__ int pixel(int k) const {
           const int q = 32 * (wp + C::WP * k) + l31;
           const int r = (int)(((float)q + 0.5f) * rpw), c = q - r * PW;
-          const int yy = cur.y0 + r;
-          const bool ok = c < W && r < R && yy < H && ch_ok;
-          const int pix = yy * W + c;
-          off_y[k] = ok ? (pix * a.ldy + c0) * 2 : (int)0x80000000;   // byte offset; out of range: the store is dropped
-          if (a.res) {   // (a pixel outside the image reads out of range: zeros)
-            const int ro = ok ? (pix * a.ldr + c0) * 2 : (int)0x80000000;
-            rv[k][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro, 0, 0));
-            rv[k][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro, 16, 0));
-          }
+          const int yy = y0 + r;
+          return (c < W && r < R && yy < H && ch_ok) ? yy * W + c : -1;
+        }
+        __device__ __forceinline__ void put(int k, int hh, const half8& o) const {
+          typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+          const int pix = pixel(k);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rs_y, pix >= 0 ? (pix * ldy + c0) * 2 : (int)0x80000000, 16 * hh, 0);
+        }
+        __device__ __forceinline__ void load_res(int k, half8 (&rv)[2]) const {
+          const int pix = pixel(k);
+          const int ro = pix >= 0 ? (pix * ldr + c0) * 2 : (int)0x80000000;
+          rv[0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro, 0, 0));
+          rv[1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rs_r, ro, 16, 0));
         }
       };
-      auto store2 = [&](int k, int hh, const half8& o) __attribute__((always_inline)) {
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, o), rs_y, off_y[k], 16 * hh, 0);
-      };
+      const int c0 = cur.ch + wc * 32 + 16 * h;
+      const Store2 store2{
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)cur.b * a.y_bstride), 0, (int)((long)H * W * a.ldy * 2), 0x00020000),
+          __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res + (long)cur.b * a.r_bstride : a.x), 0, (int)((long)H * W * (RES ? a.ldr : a.ldx) * 2), 0x00020000),
+          wp, l31, PW, W, R, H, cur.y0, a.ldy, a.ldr, c0, c0 + 16 <= a.Cout, 1.0f / (float)PW};
       const float16v bv2 = load_bias(a.bb, cur.ch);
       auto setup2 = [&](int p) __attribute__((always_inline)) {
         bool pieces = false;
@@ -457,15 +464,16 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
         st.rs_wn = __builtin_amdgcn_make_buffer_rsrc((void*)(p + 1 < npl ? wbase_b + (p + 1) * pbytes : (C::PAIR ? wbase_a : wbase_b_next)), 0, pbytes, 0x00020000);
       };
       setup2(0);
-      planes_phase<C, C::NPB2, true, 0, false>(st, bv2, rv, false, store2);
+      if (a.stamps) pst[4] = __builtin_amdgcn_s_memtime();
+      planes_phase<C, C::NPB2, true, 0, false>(st, bv2, store2);
       for (int p = 1; p + 1 < npl; ++p) {
         setup2(p);
-        planes_phase<C, C::NPB2, false, 0, true>(st, bv2, rv, false, store2);
+        if (a.stamps && p < 3) pst[4 + p] = __builtin_amdgcn_s_memtime();
+        planes_phase<C, C::NPB2, false, 0, true>(st, bv2, store2);
       }
       setup2(npl - 1);
-      prep2();
-      if (a.stamps) stamp[4] = __builtin_amdgcn_s_memtime();
-      planes_phase<C, C::NPB2, false, 2, true>(st, bv2, rv, a.res != nullptr, store2);
+      if (a.stamps) stamp[4] = pst[7] = __builtin_amdgcn_s_memtime();
+      planes_phase<C, C::NPB2, false, RES ? 3 : 2, true>(st, bv2, store2);
     }
     if (!more) break;
     vb += nwg;
@@ -485,6 +493,9 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
 #pragma unroll
     for (int i = 0; i < 6; ++i) o[i] = stamp[i];
     o[6] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o2 = a.stamps + (long)gridDim.x * 4 * 8 + ((long)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o2[i] = pst[i];
   }
 }
 
@@ -531,10 +542,11 @@ bool planes_common_ok(const PlanesArgs& a) {
 
 template <class C>
 int planes_launch(const PlanesArgs& a, const PlanesGeom& g, hipStream_t s) {
-  auto k = planes_kernel<C>;
+  auto k = a.res ? planes_kernel<C, true> : planes_kernel<C, false>;
   static int slots = 0;
   if (!slots) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    hipError_t e = hipFuncSetAttribute((const void*)planes_kernel<C, true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)planes_kernel<C, false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
     if (e != hipSuccess) return (int)e;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
@@ -559,7 +571,11 @@ bool bneck_pair_shape_ok(int C, int H, int W) {
   a.H = H; a.W = W; a.B = 1; a.Cin = a.Cout = C;
   PlanesGeom g;
   if (C == 128) return planes_geometry<P128>(a, &g);
-  if (C == 64) return planes_geometry<P64>(a, &g);
+  // 64 hidden channels: measured 58 us per pair on the 80 x 80 level at batch 32 against 56 for the two conv3x3_halo launches -- a
+  // block finishes half of its phases with the SiLU pipe beside the MFMAs (VALU-bound), and with one wave per SIMD nothing else
+  // covers it.  The instance is kept (tests, M355_PAIR64=1), the graph builder does not use it.
+  static const bool pair64 = getenv("M355_PAIR64") != nullptr;
+  if (C == 64 && pair64) return planes_geometry<P64>(a, &g);
   return false;
 }
 

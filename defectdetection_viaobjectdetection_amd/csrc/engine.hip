@@ -133,7 +133,8 @@ struct m355_engine {
   // head output convs decode in their epilogue (all three levels, else none); the raw maps are then written only on request
   bool decode_fused = false;
   int headtail_n = 0;        // head levels eligible for head_tail.hip (3: the decode launch is skipped when the raw maps are not kept)
-  int headtail_done = 0;     // ... and how many of them took it in the forward being enqueued
+  bool headtail_active = false;   // decided per forward, for ALL three levels or none: every level passes head_tail_ok for this batch
+  long headtail_maxm = 0;    // testing only (M355_HEADTAIL_MAXM at create): a level with more pixels than this counts as ineligible
   int keep_raw = 1;
   // profiling: HIP events around every op launch, recorded on the caller's stream (single lane while profiling)
   bool profiling = false;
@@ -1144,6 +1145,7 @@ int m355_create(const m355_model_desc* desc, m355_engine** out) {
   }
   m355_engine* e = new m355_engine();
   e->desc = *desc;
+  if (const char* mm = getenv("M355_HEADTAIL_MAXM")) e->headtail_maxm = atol(mm);   // testing: force a head level ineligible
   int rc = build_graph(e);
   if (rc == 0) fuse_conv_cv1(e);
   if (rc == 0) fuse_decode(e);
@@ -1392,7 +1394,23 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
     if (!e->conv_loaded[i]) return e->fail(M355_ERR_STATE, std::string("weights not set for ") + e->convs[i].name);
   hipStream_t s_main = (hipStream_t)stream;
   const int rw = 64 + e->nc + e->nm;
-  e->headtail_done = 0;
+  // head levels as conv + decode launches (head_tail.hip): all three or none.  The kernel's 31-bit byte-offset bound is reached by the
+  // stride-8 level first (batch >= 749 at 640 x 640); a per-level choice would leave the decode launch to overwrite the rows
+  // the other two levels had already written with whatever the raw buffer holds.
+  e->headtail_active = false;
+  if (!e->keep_raw && e->headtail_n == 3) {
+    bool all = true;
+    for (const Op& op : e->ops) {
+      if (!op.headtail) continue;
+      const PhysConv& p = e->phys[op.conv];
+      const Tensor& ti = e->tensors[op.in.t];
+      HeadTailArgs ha{};
+      ha.x = ti.p; ha.ldx = ti.C; ha.M = (long)B * ti.H * ti.W; ha.HW = ti.H * ti.W; ha.W = ti.W;
+      ha.nc = e->nc; ha.nm = e->nm; ha.wf = p.wf; ha.bias = p.bias; ha.preds = d_preds;
+      if (!p.wf || !head_tail_ok(ha) || (e->headtail_maxm > 0 && ha.M > e->headtail_maxm)) all = false;
+    }
+    e->headtail_active = all;
+  }
   const bool lanes = e->nlanes > 1 && !e->profiling;   // per-op event timing needs one stream
   // ops [lo, hi) over images [b0, b0 + Bq)
   auto run_range = [&](size_t lo, size_t hi, const int b0, const int Bq) -> int {
@@ -1500,17 +1518,14 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           const PhysConv& pf = e->phys[op.conv];
           a.w2 = pf.w2; a.bias2 = pf.bias2; a.cout2 = pf.cout2; a.wf2 = pf.wf2;
         }
-        if (op.headtail && !e->keep_raw && e->headtail_n == 3 && p.wf && !b0) {   // conv + decode of this level in one launch
+        if (op.headtail && e->headtail_active && !b0) {   // conv + decode of this level in one launch
           HeadTailArgs ha{};
           ha.x = ti.p; ha.ldx = ti.C; ha.M = (long)Bq * ti.H * ti.W; ha.HW = ti.H * ti.W; ha.W = ti.W;
           ha.stride = (float)(e->desc.in_h / ti.H);
           ha.A = e->A; ha.level_off = op.level_off; ha.nc = e->nc; ha.nm = e->nm;
           ha.wf = p.wf; ha.bias = p.bias; ha.preds = d_preds;
-          if (head_tail_ok(ha)) {
-            rc = launch_head_tail(ha, s);
-            ++e->headtail_done;
-            break;
-          }
+          rc = launch_head_tail(ha, s);   // (eligibility was checked for all three levels at the top of this forward)
+          break;
         }
         a.tileq = knobs().static_tiles ? nullptr : e->tileq + 4 * oi;
         if (op.stemfuse >= 0) {
@@ -1618,7 +1633,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
       }
       case OP_DECODE:
         if (e->decode_fused) break;   // the three head output convs wrote the prediction rows
-        if (e->headtail_done == 3) break;   // so did the three head_tail launches of this forward
+        if (e->headtail_active) break;   // so did the three head_tail launches of this forward
         rc = launch_head_decode(e->raw, Bq, e->desc.in_h, e->desc.in_w, e->nc, e->nm, d_preds, s);
         break;
     }
@@ -1934,7 +1949,7 @@ int m355_bneck_pair_fwd(const void* d_x, int B, int H, int W, int C, int ldx, co
   if (shortcut) { a.res = a.x; a.r_bstride = a.x_bstride; a.ldr = ldx; }
   unsigned long long* d_st = nullptr;
   const char* st_path = getenv("M355_STAMPS");
-  const size_t st_n = (size_t)256 * 4 * 8;
+  const size_t st_n = (size_t)256 * 4 * 8 * 2;
   if (st_path) {
     HIP_TRYG(hipMalloc((void**)&d_st, st_n * 8));
     HIP_TRYG(hipMemset(d_st, 0, st_n * 8));

@@ -508,6 +508,36 @@ def test_head_levels_as_conv_plus_decode_launches(cuda_device, shape, batch, nc)
     assert torch.equal(a, b)
 
 
+def test_head_tail_is_all_levels_or_none(cuda_device):
+    """The head_tail launch is chosen for all three head levels of a forward or for none (engine.hip, top of m355_forward): its 31-bit
+    byte-offset bound is reached by the stride-8 level first (batch >= 749 at 640 x 640), and a per-level choice would let the decode
+    launch overwrite the rows the two smaller levels had written with whatever the raw buffer holds (round-3 advisor finding).
+    M355_HEADTAIL_MAXM (testing knob, read at m355_create) makes every level with more pixels than that ineligible: with the
+    stride-8 level forced out, the predictions must be those of the im2col + decode path, bit for bit."""
+    import os
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(3, seed=53)[:, :320, :320].copy()).to(cuda_device)
+    outs = {}
+    for name, keep, maxm in (("reference", True, None), ("forced_out", False, 3 * 20 * 20 + 1), ("head_tail", False, None)):
+        if maxm is not None:
+            os.environ["M355_HEADTAIL_MAXM"] = str(maxm)      # 3 x 40 x 40 pixels of the stride-8 level exceed it, the other two do not
+        try:
+            eng = SegEngine("s", 1, (320, 320), max_batch=3, keep_raw=keep)
+        finally:
+            os.environ.pop("M355_HEADTAIL_MAXM", None)
+        eng.load_state_dict(sd)
+        eng.forward(imgs)                                      # (a first forward leaves stale rows in the raw buffer)
+        p, _ = eng.forward(torch.flip(imgs, (0,)))
+        torch.cuda.synchronize()
+        outs[name] = p.clone()
+        eng.close()
+    assert torch.isfinite(outs["forced_out"]).all()
+    assert torch.equal(outs["forced_out"], outs["reference"])
+    assert torch.equal(outs["head_tail"], outs["reference"])
+
+
 def test_stem_fused_into_the_patch_kernel_matches_the_two_launches(cuda_device):
     """model.0 + model.1 + model.2.cv1 in one launch (conv_stem_s2c32.hip: the patch of the stem output is computed from the
     uint8 window in LDS and never stored) against stem launch + patch kernel.  Same MFMA shape and tap order for the stem, so

@@ -17,8 +17,14 @@ for (H, W, Cc) in ((40, 40, 128), (80, 80, 64), (20, 20, 128)):
     if rc != 0:
         print((H, W, Cc), "refused")
         continue
-    s = np.fromfile("/tmp/bneck_stamps.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
-    s = s[s[:, 0] > 0]
+    raw = np.fromfile("/tmp/bneck_stamps.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+    nb = min(256, B * 100)
+    s = raw[:1024]
+    keep = s[:, 0] > 0
+    ph = raw[1024:2048][keep]
+    s = s[keep]
+    d2 = np.diff(np.concatenate([ph, s[:, 5:6]], axis=1), axis=1)
+    print("     per-phase cycles (conv1 p0, p1, p2, last+transition | conv2 p0, p1, p2, last+epilogue): " + " ".join(str(int(np.median(d2[:, i]))) for i in range(8)))
     d = np.diff(s[:, :6], axis=1)
     names = ["prologue", "conv1", "transition", "conv2", "epilogue(last tile)"]
     print(f"  {(B, H, W, Cc)}: waves {len(s)}; median cycles: " + ", ".join(f"{n} {int(np.median(d[:, i]))}" for i, n in enumerate(names)) +
