@@ -79,7 +79,7 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_SLAB = 25, TILE_M32 = 26, TILE_M32_128 = 27, TILE_M32_64x16 = 28, TILE_M32_64x8 = 29, TILE_C64R = 30, TILE_C128R = 31, TILE_W1 = 32 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_SLAB = 25, TILE_M32 = 26, TILE_M32_128 = 27, TILE_M32_64x16 = 28, TILE_M32_64x8 = 29, TILE_C64R = 30, TILE_C128R = 31, TILE_W1 = 32, TILE_PLANES = 33 };
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {

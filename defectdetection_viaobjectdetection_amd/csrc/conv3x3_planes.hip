@@ -26,8 +26,8 @@
 // GEMM orientation as in conv3x3_m32.hip: D[channel][pixel], weights = A operand, rows permuted on the DMA source side so
 // that a lane-half owns 16 consecutive channels of its pixel (two 16-byte stores / LDS writes per pixel block).
 //
-// Block = 4 waves, one per SIMD (launch_bounds(256, 1): up to 512 VGPRs): wave = (channel block wc of WC, pixel group wp of
-// WP = 4 / WC), NPB pixel blocks each (accumulators: 16 x NPB VGPRs).  K loop: phase = one input plane (32 channels), step =
+// Block = 4 waves, one per SIMD (up to 512 VGPRs; the 64-channel instance: 8 waves, two per SIMD): wave = (channel block wc of WC,
+// pixel group wp of WP = waves / WC), NPB pixel blocks each (accumulators: 16 x NPB VGPRs).  K loop: phase = one input plane (32 channels), step =
 // one tap = 2 MFMA slices of K = 16.  Weight ring of four stages: the stage of step g + 3 is issued in step g, a step waits
 // (counted vmcnt) for the stage of step g + 1 only.  Input planes: ring of two; the pieces of plane p + 1 are issued during
 // the first six steps of phase p.  ONE barrier per step.
@@ -60,12 +60,17 @@ struct PlanesGeom {
   int off_x, off_s;         // LDS byte offsets: input ring, one spare KiB behind it (reads of never-stored pixel blocks may run past a slot)
 };
 
-template <int WC_, int NPB1_, int NPB2_, bool PAIR_, int PPS_>
+template <int WC_, int NPB1_, int NPB2_, bool PAIR_, int PPS_, int NW_ = 4>
 struct PCfg {
-  static constexpr int WC = WC_, WP = 4 / WC_, NPB1 = NPB1_, NPB2 = NPB2_, PPS = PPS_;
+  static constexpr int NW = NW_;                  // waves per block: 4 (one per SIMD) or 8 (two: the VALU pipe of one beside the MFMAs of the other)
+  static constexpr int WC = WC_, WP = NW_ / WC_, NPB1 = NPB1_, NPB2 = NPB2_, PPS = PPS_;
   static constexpr bool PAIR = PAIR_;
   static constexpr int NB1 = WP * NPB1, NB2 = WP * NPB2;
   static constexpr int NPB = NPB1 > NPB2 ? NPB1 : NPB2;
+  // B fragment FIFO (registers): FQ divides the 18 fragments of a pixel block, so every phase starts at slot 0; FD fragments in
+  // flight: eight with one wave per SIMD (an LDS read returns within eight MFMAs also when all four waves stream), two with two
+  // waves per SIMD (256 registers per wave; the partner's MFMAs cover the wait)
+  static constexpr int FQ = NW_ == 4 ? 9 : 3, FD = NW_ == 4 ? 8 : 2;
   static constexpr int PIT = 6 * PPS;             // input pieces per wave and plane
   static constexpr int KSTEP = 2048 * WP;         // LDS bytes between consecutive pixel blocks of one wave
   static_assert(WC == 2 || WC == 4, "channel blocks per block");
@@ -82,14 +87,12 @@ __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-constexpr int FQ = 9;   // B fragment FIFO (registers): 18 fragments per pixel block, so every phase starts at slot 0
-constexpr int FD = 8;   // fragments in flight (an LDS read returns within eight MFMAs also when all four waves stream)
 
 template <class C>
 struct PState {
   float16v acc[C::NPB];
   half8 A[18];                // the phase's weight fragments (MFMA A operands): (tap, slice) -> 2 * tap + slice
-  half8 bq[FQ];
+  half8 bq[C::FQ];
   int tb[9];                  // B fragment: LDS byte offset inside a plane for (tap, slice 0), pixel block 0 of this wave
   int pvoff[C::PIT];          // per-lane source offsets of the input pieces of the slab the loader is on
   __amdgpu_buffer_rsrc_t rs_x;
@@ -123,7 +126,7 @@ __device__ __forceinline__ half_t to_half_rn(float v) {
 template <int NPBC>
 struct PostPipe {
   float t[8];            // running temporaries, by c % 8
-  float y[16];           // finished values of the block in flight (packed two slots after the second of a pair)
+  float y[4];            // finished values, by c % 4 (a pair is packed one or two slots after its second value)
   half8 o[2];            // the two 16-byte halves of a pixel's 16 channels
   half8 rv[2][2];        // mode 3: the residual of the block in the pipe / of the next one (loaded one block ahead, an L2 hit)
 };
@@ -150,11 +153,11 @@ __device__ __forceinline__ void post_slot(PState<C>& st, PostPipe<NPBC>& pp, Sto
   if constexpr (B::on) pp.t[B::c % 8] = __builtin_amdgcn_exp2f(pp.t[B::c % 8]);
   if constexpr (Cc::on) pp.t[Cc::c % 8] = 1.0f + pp.t[Cc::c % 8];
   if constexpr (D::on) pp.t[D::c % 8] = __builtin_amdgcn_rcpf(pp.t[D::c % 8]);
-  if constexpr (E::on) pp.y[E::c] = st.acc[E::kk][E::c] * pp.t[E::c % 8];
-  if constexpr (MODE == 3 && F::on) pp.y[F::c] = __builtin_fmaf((float)pp.rv[F::kk & 1][F::c / 8][F::c % 8], 1.0f, pp.y[F::c]);   // = y + residual, one v_fma_mix
+  if constexpr (E::on) pp.y[E::c % 4] = st.acc[E::kk][E::c] * pp.t[E::c % 8];
+  if constexpr (MODE == 3 && F::on) pp.y[F::c % 4] = __builtin_fmaf((float)pp.rv[F::kk & 1][F::c / 8][F::c % 8], 1.0f, pp.y[F::c % 4]);   // = y + residual, one v_fma_mix
   if constexpr (P::on && (P::c & 1)) {
-    pp.o[P::c / 8][(P::c % 8) - 1] = to_half_rn(pp.y[P::c - 1]);
-    pp.o[P::c / 8][P::c % 8] = to_half_rn(pp.y[P::c]);
+    pp.o[P::c / 8][(P::c % 8) - 1] = to_half_rn(pp.y[(P::c - 1) % 4]);
+    pp.o[P::c / 8][P::c % 8] = to_half_rn(pp.y[P::c % 4]);
   }
   if constexpr (W::on && (W::c % 8) == 7) store.put(W::kk, W::c / 8, pp.o[W::c / 8]);
 }
@@ -173,16 +176,14 @@ template <class C, int NPBC, bool FIRST, int MODE, bool PRIMED, class Store>
 __device__ __forceinline__ void planes_phase(PState<C>& st, const float16v& bv, Store&& store) {
   constexpr int N = NPBC * 18;
   constexpr int PSTEP = 3;                                       // slots between two input pieces
-  int addr[18];
+  constexpr int FQ = C::FQ, FD = C::FD;
+  int addr[9];   // slice 0 of the nine taps; slice 1 = ^ 32 (the planes start at multiples of 64 bytes)
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    addr[2 * t] = st.pcur + st.tb[t];
-    addr[2 * t + 1] = addr[2 * t] ^ 32;
-  }
+  for (int t = 0; t < 9; ++t) addr[t] = st.pcur + st.tb[t];
   PostPipe<NPBC> pp;
   if (!PRIMED) {
 #pragma unroll
-    for (int n = 0; n < FD; ++n) st.bq[n % FQ] = *(const half8*)(st.smem + addr[n % 18] + (n / 18) * C::KSTEP);
+    for (int n = 0; n < FD; ++n) st.bq[n % FQ] = *(const half8*)(st.smem + (addr[(n % 18) / 2] ^ ((n & 1) << 5)) + (n / 18) * C::KSTEP);
   }
   static_for<N>([&](auto nc) __attribute__((always_inline)) {
     constexpr int n = decltype(nc)::value;
@@ -201,7 +202,7 @@ __device__ __forceinline__ void planes_phase(PState<C>& st, const float16v& bv, 
       st.acc[k] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.A[i], st.bq[n % FQ], st.acc[k], 0, 0, 0);
     if constexpr (n + FD < N) {
       constexpr int m = n + FD;
-      st.bq[m % FQ] = *(const half8*)(st.smem + addr[m % 18] + (m / 18) * C::KSTEP);
+      st.bq[m % FQ] = *(const half8*)(st.smem + (addr[(m % 18) / 2] ^ ((m & 1) << 5)) + (m / 18) * C::KSTEP);
     } else if constexpr (MODE == 0) {
       constexpr int m = n + FD - N;   // the next phase's fragment m (its block 0)
       st.bq[m % FQ] = *(const half8*)(st.smem + st.pnext + (st.tb[m / 2] ^ ((m & 1) << 5)));
@@ -218,7 +219,7 @@ __device__ __forceinline__ void planes_phase(PState<C>& st, const float16v& bv, 
     if constexpr (n >= 1 && (n - 1) % PSTEP == 0 && (n - 1) / PSTEP < C::PIT) {
       constexpr int m = (n - 1) / PSTEP;
       const bool real = m < st.nreal;
-      dma16(st.rs_x, real ? st.pvoff[m] : (int)0x80000000, st.px_soff, st.smem + (real ? st.px_dst + m * 4096 : st.off_s));
+      dma16(st.rs_x, real ? st.pvoff[m] : (int)0x80000000, st.px_soff, st.smem + (real ? st.px_dst + m * (C::NW * 1024) : st.off_s));
     }
     // block k's residual: first used in slot 18 (k + 1) + 6; the buffer's previous tenant (block k - 2) was last read in slot 18 k + 3
     if constexpr (MODE == 3 && i == 5) store.load_res(k, pp.rv[k & 1]);
@@ -239,7 +240,7 @@ struct PTile {
 };
 
 template <class C, bool RES>
-__global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, const PlanesGeom g) {
+__global__ __launch_bounds__(64 * C::NW, C::NW / 4) void planes_kernel(const PlanesArgs a, const PlanesGeom g) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   st.off_s = g.off_s;
   const int pbytes = 18 * 1024;                          // fragments of one phase
   const long wblock = (long)pbytes * g.NP;               // ... of one channel block of one convolution
-  const int nreal_wave = (g.npieces - wave + 3) / 4;     // pieces of a plane this wave issues
+  const int nreal_wave = (g.npieces - wave + C::NW - 1) / C::NW;     // pieces of a plane this wave issues
   const int img_stride = (int)a.x_bstride * 2;
   st.rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((a.B - 1) * a.x_bstride + (long)H * W * a.ldx) * 2, 0x00020000);
 
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   auto piece_offsets = [&](const PTile& t) __attribute__((always_inline)) {
 #pragma unroll
     for (int m = 0; m < C::PIT; ++m) {
-      const int j = 16 * (wave + 4 * m) + lrow;
+      const int j = 16 * (wave + C::NW * m) + lrow;
       const int rj = j / PW, cj = j - rj * PW;
       const int iy = t.y0 - HALO + rj, ix = cj - 1;
       const bool ok = j < xrows_valid && cj >= 1 && (unsigned)iy < (unsigned)H;
@@ -331,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   piece_offsets(cur);
 #pragma unroll
   for (int m = 0; m < C::PIT; ++m) {
-    const int k = wave + 4 * m;
+    const int k = wave + C::NW * m;
     if (k < g.npieces) dma16(st.rs_x, st.pvoff[m], cur.b * img_stride, smem + g.off_x + k * 1024);
   }
   load_frags(C::PAIR ? wbase_a : wbase_b, st.A);
@@ -489,11 +490,11 @@ __global__ __launch_bounds__(256, 1) void planes_kernel(const PlanesArgs a, cons
   }
   if (a.stamps && lane == 0) {
     stamp[5] = __builtin_amdgcn_s_memtime();
-    unsigned long long* o = a.stamps + ((long)blockIdx.x * 4 + wave) * 8;
+    unsigned long long* o = a.stamps + ((long)blockIdx.x * C::NW + wave) * 8;
 #pragma unroll
     for (int i = 0; i < 6; ++i) o[i] = stamp[i];
     o[6] = __builtin_amdgcn_s_memrealtime();
-    unsigned long long* o2 = a.stamps + (long)gridDim.x * 4 * 8 + ((long)blockIdx.x * 4 + wave) * 8;
+    unsigned long long* o2 = a.stamps + (long)gridDim.x * C::NW * 8 + ((long)blockIdx.x * C::NW + wave) * 8;
 #pragma unroll
     for (int i = 0; i < 8; ++i) o2[i] = pst[i];
   }
@@ -510,7 +511,7 @@ bool planes_geometry(const PlanesArgs& a, PlanesGeom* g) {
   const int NP = a.Cin / 32;
   for (; R >= 1; --R) {
     const int npieces = ((R + 2 * HALO) * PW + 1 + 15) / 16;
-    if (npieces > 4 * C::PIT) continue;
+    if (npieces > C::NW * C::PIT) continue;
     const int inter = C::PAIR ? C::WC * 32 * C::NB1 * ROWB : 0;
     if (inter + 2 * npieces * 1024 + 1024 > LDS_MAX) continue;
     break;
@@ -555,12 +556,13 @@ int planes_launch(const PlanesArgs& a, const PlanesGeom& g, hipStream_t s) {
     if (slots < 8) slots = 8;
   }
   const int grid = g.ntiles <= slots ? g.ntiles : slots;
-  hipLaunchKernelGGL(k, dim3(grid), dim3(256), g.off_s + 1024, s, a, g);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(64 * C::NW), g.off_s + 1024, s, a, g);
   return (int)hipGetLastError();
 }
 
 using P128 = PCfg<4, 9, 7, true, 1>;    // 128 hidden channels: 40 x 40 maps in slabs of 5 rows (9 / 7 pixel blocks per wave)
-using P64 = PCfg<2, 8, 6, true, 2>;     // 64 hidden channels: 80 x 80 maps in slabs of 4 rows (16 / 12 pixel blocks over two pixel groups)
+using P64 = PCfg<2, 8, 6, true, 2>;     // 64 hidden channels: 80 x 80 maps in slabs of 4 rows (16 / 12 pixel blocks over two pixel groups).  (Measured on eight
+                                        // waves, <2, 4, 3, true, 1, 8>: 256 registers per wave do not hold the pipe -- 70 spills, 91 us per pair.)
 using S64 = PCfg<2, 0, 4, false, 1>;    // single conv, 64-channel tiles: 20 x 20 maps in slabs of 10 rows
 
 }  // namespace

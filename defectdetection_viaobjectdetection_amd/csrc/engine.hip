@@ -908,7 +908,22 @@ void annotate_ops(m355_engine* e) {
           if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && op.tile != TILE_C64R && op.tile != TILE_C128R && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
             op.tile = TILE_SLAB;
         }
-        if (op.tile == TILE_W1)
+        // row-slab kernel in single-conv mode (conv3x3_planes.hip) for what the slab kernel took (the 20 x 20 level): one block per CU
+        // owns a slab x 64 channels with its weights streamed to registers -- 21 us against 34 on 256 -> 256 at batch 32
+        if (op.kind == OP_CONV && op.tile == TILE_SLAB && op.out_ext == 0 && p.l3 < 0 && !p.diag && !getenv("M355_NO_PLANES")) {
+          const Tensor& to2 = e->tensors[op.out.t];
+          PlanesArgs pa{};
+          pa.x = ti.p; pa.y = to2.p; pa.wfb = (const half_t*)1; pa.bb = (const float*)1;   // (shape check only)
+          pa.x_bstride = (long)ti.H * ti.W * ti.C; pa.ldx = ti.C; pa.H = ti.H; pa.W = ti.W; pa.B = e->desc.max_batch; pa.Cin = p.cin; pa.Cout = p.cout;
+          pa.cblocks_b = (p.cout + 63) / 64 * 2; pa.ldy = to2.C; pa.act = p.act;
+          if (conv3x3_planes_ok(pa)) {
+            op.tile = TILE_PLANES;
+            e->phys[op.conv].planes = 1;
+          }
+        }
+        if (op.tile == TILE_PLANES)
+          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_planes<64ch,rows>");
+        else if (op.tile == TILE_W1)
           snprintf(op.kernel, sizeof(op.kernel), "conv1x1_wreg<K%d,%dch>", p.cin, cout_v % 256 == 0 ? 256 : 128);
         else if (op.tile == TILE_C128R)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c128r<128ch,8x8px>");
@@ -1360,13 +1375,17 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
         }
       }
     }
-    if (p.planes && p.logical.size() == 1 && ci.k == 3 && ci.cin % 32 == 0) {   // K-loop fragment order of the row-slab kernels, channel blocks padded with zero rows
-      const int cbl = (ci.cout + 63) / 64 * 2;
-      std::vector<half_t> padded((size_t)cbl * 32 * p.Kpad, (half_t)0.f);
-      std::copy(rows.begin(), rows.end(), padded.begin());
-      const auto fp = planes_frag_pack(padded.data(), p.Kpad, ci.cin, cbl);
-      if (!p.wf) HIP_TRY(e, hipMalloc((void**)&p.wf, fp.size() * sizeof(half_t)));
-      HIP_TRY(e, hipMemcpy(p.wf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    if (p.planes && ci.k == 3 && p.cin % 32 == 0 && !p.diag && p.l3 < 0) {   // K-loop fragment order of the row-slab kernels, channel blocks padded with zero rows
+      bool all = true;   // (a launch shared by several logical convs -- the head's first layer -- packs once all of them are here)
+      for (int li : p.logical) all = all && (li == idx || e->conv_loaded[li]);
+      if (all) {
+        const int cbl = (p.cout + 63) / 64 * 2;
+        std::vector<half_t> padded((size_t)cbl * 32 * p.Kpad, (half_t)0.f);
+        HIP_TRY(e, hipMemcpy(padded.data(), p.w, (size_t)p.cout * p.Kpad * sizeof(half_t), hipMemcpyDeviceToHost));
+        const auto fp = planes_frag_pack(padded.data(), p.Kpad, p.cin, cbl);
+        if (!p.wf) HIP_TRY(e, hipMalloc((void**)&p.wf, fp.size() * sizeof(half_t)));
+        HIP_TRY(e, hipMemcpy(p.wf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+      }
     } else if ((p.logical.size() == 1 || (p.l3 >= 0 && !p.composed && idx == p.logical[0])) && !p.diag && row0 == 0) {   // fragment-ordered copies for the weights-in-registers kernels
       const auto fl = frag_list(ci.k, ci.cin, ci.cout);
       if (!fl.empty()) {
@@ -1548,6 +1567,15 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           }
           rc = launch_stem(sa, s);            // not eligible after all (shape): the two launches
           if (rc != 0) break;
+        }
+        if (op.tile == TILE_PLANES) {
+          PlanesArgs pa{};
+          pa.x = a.x; pa.x_bstride = a.x_bstride; pa.ldx = a.ldx; pa.H = a.Hi; pa.W = a.Wi; pa.B = Bq; pa.Cin = p.cin; pa.Cout = p.cout;
+          pa.wfb = p.wf; pa.cblocks_b = (p.cout + 63) / 64 * 2; pa.bb = p.bias; pa.act = p.act;
+          pa.y = (half_t*)a.y; pa.y_bstride = a.y_bstride; pa.ldy = a.ldy;
+          pa.res = a.res; pa.r_bstride = a.r_bstride; pa.ldr = a.ldr;
+          rc = (p.wf && conv3x3_planes_ok(pa)) ? launch_conv3x3_planes(pa, s) : launch_conv3x3_slab(a, s);
+          break;
         }
         rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
              : (op.s2c64 && conv_s2c64_cv1_ok(a)) ? launch_conv_s2c64_cv1(a, s)
@@ -1787,6 +1815,8 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
     int bch = 0, bpx = 0;
     if (!conv_forced_tile_extent(force_tile & 0xff, cout_v, &bch, &bpx))
       return set_err(M355_ERR_INVALID, "unknown forced tile id " + std::to_string(force_tile & 0xff));
+    if ((force_tile & 0xff) == TILE_PLANES && (transposed || k != 3 || stride != 1 || cin % 32 || out_f32))
+      return set_err(M355_ERR_INVALID, "forced tile TILE_PLANES takes 3x3 / stride 1 convs with cin % 32 == 0 and fp16 output only");
     if ((cout_v + bch - 1) / bch * bch > cout_pad)
       return set_err(M355_ERR_INVALID, "forced tile reads " + std::to_string((cout_v + bch - 1) / bch * bch) +
                                            " weight rows, the packed buffer has " + std::to_string(cout_pad));
@@ -1846,6 +1876,34 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
     a.stamps = d_st;
   }
   int rc = 0;
+  half_t* dpf = nullptr;
+  if (force_tile >= 0 && (force_tile & 0xff) == TILE_PLANES) {   // row-slab kernel (conv3x3_planes.hip), single-conv mode
+    const int cbl = (cout + 63) / 64 * 2;
+    std::vector<half_t> padded((size_t)cbl * 32 * Kpad, (half_t)0.f);
+    std::copy(rows.begin(), rows.begin() + (size_t)cout * Kpad, padded.begin());
+    const auto fp = planes_frag_pack(padded.data(), Kpad, cin, cbl);
+    HIP_TRYG(hipMalloc((void**)&dpf, fp.size() * sizeof(half_t)));
+    HIP_TRYG(hipMemcpy(dpf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
+    PlanesArgs pa{};
+    pa.x = a.x; pa.x_bstride = a.x_bstride; pa.ldx = a.ldx; pa.H = H; pa.W = W; pa.B = B; pa.Cin = cin; pa.Cout = cout;
+    pa.wfb = dpf; pa.cblocks_b = cbl; pa.bb = db; pa.y = (half_t*)d_y; pa.y_bstride = a.y_bstride; pa.ldy = a.ldy;
+    pa.res = a.res; pa.r_bstride = a.r_bstride; pa.ldr = a.ldr; pa.act = act; pa.stamps = d_st;
+    rc = conv3x3_planes_ok(pa) ? launch_conv3x3_planes(pa, s) : -1;
+    if (const char* reps = getenv("M355_BNECK_REPS")) {
+      const int n = atoi(reps);
+      hipEvent_t e0, e1;
+      if (rc == 0 && n > 0 && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&e1) == hipSuccess) {
+        (void)hipEventRecord(e0, s);
+        for (int i = 0; i < n && rc == 0; ++i) rc = launch_conv3x3_planes(pa, s);
+        (void)hipEventRecord(e1, s);
+        (void)hipEventSynchronize(e1);
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "conv3x3_planes B=%d %dx%d %d->%d: %.2f us per launch (%d launches)\n", B, H, W, cin, cout, ms * 1e3f / n, n);
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+      }
+    }
+  } else
   for (int rep = 0; rep < (a.dbg ? 5 : 1); ++rep)
     rc = (force_tile >= 0 && (force_tile & 0xff) == TILE_C64R) ? launch_conv3x3_c64r(a, s)
          : (force_tile >= 0 && (force_tile & 0xff) == TILE_C128R) ? launch_conv3x3_c128r(a, s)
@@ -1864,6 +1922,7 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
   if (d_st) (void)hipFree(d_st);
   (void)hipFree(dw); (void)hipFree(db); (void)hipFree(dz);
   if (dwf) (void)hipFree(dwf);
+  if (dpf) (void)hipFree(dpf);
   if (rc != 0) return set_err(M355_ERR_HIP, "conv launch failed: " + std::to_string(rc));
   if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("conv kernel: ") + hipGetErrorString(se));
   return M355_OK;

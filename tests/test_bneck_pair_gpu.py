@@ -93,3 +93,42 @@ def test_bneck_pair_refuses_what_it_cannot_tile(cuda_device):
     rc = _capi.lib.m355_bneck_pair_fwd(C.c_void_p(x.data_ptr()), 1, 4, 700, 128, 128, _h(z), _h(z), _h(z), _h(z), 1,
                                        C.c_void_p(x.data_ptr()), 128, None)
     assert rc != 0            # a 700-pixel row does not fit the pixel blocks of one slab
+
+
+SINGLE_CASES = [
+    # B, H, W, cin, cout, residual
+    (3, 20, 20, 256, 256, False),     # the stride-32 level at 640 x 640: two slabs of 10 rows, four 64-channel tiles
+    (2, 20, 20, 256, 256, True),
+    (2, 20, 20, 256, 64, False),      # head: cv2.2.0
+    (2, 14, 14, 256, 128, False),     # one slab per image
+    (1, 13, 17, 128, 192, True),      # ragged map, three channel tiles
+    (40, 20, 20, 256, 256, False),    # 320 tiles over 256 blocks: the prefetch across tiles, the next tile's channel blocks
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,res", SINGLE_CASES)
+def test_conv3x3_planes_single_against_torch(cuda_device, B, H, W, cin, cout, res):
+    """The row-slab kernel in single-conv mode (TILE_PLANES = 33 of m355_conv2d_fwd): y = SiLU(conv3x3(x) + b) (+ residual) against
+    fp32 F.conv2d on the fp16-rounded operands, rel-L2 <= 1e-3 like every other conv kernel."""
+    from defectdetection_viaobjectdetection_amd import _capi
+    g = torch.Generator().manual_seed(B * 100 + H + cin + cout)
+    r16 = lambda t: t.half().float()
+    x = (torch.randn((B, cin, H, W), generator=g) * 0.8).half()
+    w = r16(torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.3
+    r = (torch.randn((B, cout, H, W), generator=g)).half() if res else None
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda_device)
+    rd = r.permute(0, 2, 3, 1).contiguous().to(cuda_device) if res else None
+    yd = torch.full((B, H, W, cout), float("nan"), dtype=torch.float16, device=cuda_device)
+    wn, bn = w.numpy().astype(np.float32).copy(), b.numpy().astype(np.float32).copy()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _capi.check(_capi.lib.m355_conv2d_fwd(C.c_void_p(xd.data_ptr()), B, H, W, cin, _h(wn), _h(bn), cout, 3, 1, 1,
+                                          C.c_void_p(rd.data_ptr() if res else 0), C.c_void_p(yd.data_ptr()), 0, 33, st))
+    got = yd.float().cpu().permute(0, 3, 1, 2)
+    want = F.silu(F.conv2d(x.float(), w, b, padding=1))
+    if res:
+        want = want + r.float()
+    assert torch.isfinite(got).all()
+    rel = float((got - want).norm() / want.norm())
+    print(f"B={B} {H}x{W} {cin}->{cout} res={res}: rel-L2 {rel:.2e}")
+    assert rel <= 1e-3

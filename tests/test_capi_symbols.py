@@ -56,7 +56,7 @@ def test_forced_tile_ids_are_validated_before_any_device_work():
     w = np.zeros((128, 64, 1, 1), np.float32)
     b = np.zeros(128, np.float32)
     fake_dev = ctypes.c_void_p(0x1000)   # never dereferenced: the rejection precedes every HIP call
-    for bad in (4, 6, 7, 21, 22, 23, 24, 33, 34, 200, 255, 0x100 | 7):   # (21-24: the lean template removed in round 3; 30-32 now exist)
+    for bad in (4, 6, 7, 21, 22, 23, 24, 33, 34, 200, 255, 0x100 | 7):   # (21-24: the lean template removed in round 3; 30-32 exist; 33 = the row-slab kernel: 3x3 only, this call is 1x1)
         rc = _capi.lib.m355_conv2d_fwd(fake_dev, 1, 8, 8, 64, w.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p),
                                        128, 1, 1, 1, None, fake_dev, 0, bad, None)
         assert rc == -1, (bad, rc)
