@@ -54,9 +54,9 @@ def main():
     ap.add_argument("--serial", action="store_true",
                     help="one engine, one stream lane inside it (M355_NO_LANES), whole-batch launches (M355_NO_SUBBATCH): every kernel runs alone, so rocprofv3's "
                          "per-kernel averages and the live event samples describe the same launches")
-    ap.add_argument("--profile-every", type=int, default=100,
-                    help="record per-op HIP events on every n-th timed step (an event pair per launch costs "
-                         "~8 us of serialisation, ~0.6 ms per fully instrumented step)")
+    ap.add_argument("--profile-steps", type=int, default=4,
+                    help="event-sampled steps (forward alone, a HIP event pair per launch) run AFTER the timed region; at least 2")
+    ap.add_argument("--profile-every", type=int, default=100, help="(ignored since round 4: no step of the timed region is event-sampled)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -170,19 +170,11 @@ def main():
     if profile:
         for e_ in engs:
             e_.collect_op_times()  # drain + reset
-    sampled = 0
+    # The timed region is the plain loop: K steps, nothing else.  (Round 3 ran the event-sampled steps INSIDE it; a sampled step
+    # drains and refills the pipeline, ~2.5 ms, so the figure depended on --steps: 6.5 % of a 20-step run.)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        # every n-th step counted back from the LAST one (a run shorter than n samples its last step only).  A sampled step
-        # gives up all overlap: the pipeline drains before it and refills after it -- the last step has no refill to pay.
-        on = profile and (args.steps - 1 - i) % args.profile_every == 0
-        cur = engs[step_no[0] % n_eng]
-        if on:
-            cur.set_profiling(True)
-            sampled += 1
-        step(alone=on)
-        if on:
-            cur.set_profiling(False)
+        step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -192,6 +184,17 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # Event-sampled steps, AFTER the clock has been read: each runs its forward alone (no other forward, no post-processing beside
+    # it) with a HIP event pair around every launch, on the stream the kernels are launched on.
+    sampled = 0
+    if profile:
+        for i in range(max(2, args.profile_steps)):
+            cur = engs[step_no[0] % n_eng]
+            cur.set_profiling(True)
+            step(alone=True)
+            cur.set_profiling(False)
+            sampled += 1
+        torch.cuda.synchronize()
     ms_sum, cnt = [], []
     if profile:
         for e_ in engs:   # every engine has the same op list: add the samples up
@@ -263,6 +266,25 @@ def main():
                                   "gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 else 0.0}
                               for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])}
             out["forward_ms_per_step_events"] = round(fwd_ms, 4)
+            # the north-star set: the 3x3 convolutions of the C2f bottlenecks (20 layers at the s scale: SURVEY 8d, 9.44 GFLOP per
+            # image).  Sum of their algorithmic FLOPs over the sum of the event times of the launches that compute them; a fused
+            # launch (a whole Bottleneck; model.2's block with its 1x1) is counted with its whole time and its 3x3 FLOPs only.
+            cf = {"flops": 0.0, "ms": 0.0, "launches": 0, "layers": 0}
+            for info, ms, c in zip(infos, ms_sum, cnt):
+                if c == 0 or ".m." not in info["layer"]:
+                    continue
+                fused_block = info["kernel"].startswith("c2f_c32")          # two 3x3 (32 -> 32) + the 1x1 (96 -> 64): 18432 of 24576 MACs per pixel
+                share = 18432.0 / 24576.0 if fused_block else 1.0
+                cf["ms"] += ms
+                cf["launches"] += c
+                cf["layers"] += (2 if ("+cv2" in info["layer"]) else 1) * c
+                cf["flops"] += share * info["flops"] * B * c
+            if cf["ms"] > 0:
+                tf = cf["flops"] / (cf["ms"] * 1e-3) / 1e12
+                out["c2f3x3"] = {"tflops": round(tf, 1), "frac_of_mfma_peak": round(tf / MFMA_PEAK_TFLOPS, 4), "peak": MFMA_PEAK_TFLOPS,
+                                 "ms_per_step": round(cf["ms"] / max(sampled, 1), 4), "launches_per_step": cf["launches"] // max(sampled, 1),
+                                 "layers": cf["layers"] // max(sampled, 1), "gflop_per_image": round(cf["flops"] / max(sampled, 1) / B / 1e9, 3),
+                                 "target_frac": 0.70}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.scale, sd)
     if not args.no_train:

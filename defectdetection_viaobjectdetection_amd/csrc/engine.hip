@@ -2235,6 +2235,7 @@ int m355_conv_launch(const m355_conv_args* c, void* stream) {
     rc = launch_conv1x1_wreg(a, (hipStream_t)stream);
   else if (train_c32 && !a.tmode && conv3x3_c32_ok(a) && conv_rows_covered(a, 32))
     rc = launch_conv3x3_c32(a, (hipStream_t)stream);
+  // (3x3 / s1 on the 20 x 20 level through conv3x3_slab: measured 26.6 ms per step against 26.2 on the im2col kernel at batch 64 -- not taken)
   else
     rc = launch_conv_igemm(a, TILE_AUTO, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "conv launch failed: " + std::to_string(rc));

@@ -42,7 +42,9 @@ def _oracle_grads_v9c(nc, sd, x, R1, R2, batch, emulate):
 def test_v9c_train_forward_backward_parity(cuda_device):
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
     from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
-    nc, shape, batch = 1, (128, 160), 2
+    # 320 x 320, batch 2: the smallest batch-norm maps (stride 32) hold 200 pixels -- at 128 x 160 they held 40 and train-mode statistics on
+    # so few values amplified the fp16 storage noise to a floor of 8.7e-2, a bound that caught little (round-3 verdict)
+    nc, shape, batch = 1, (320, 320), 2
     sd = synthetic_state_dict("9c", nc, seed=3)
     eng = TrainEngine("9c", nc, shape, batch)
     eng.load_state_dict(sd)
@@ -60,7 +62,8 @@ def test_v9c_train_forward_backward_parity(cuda_device):
     e_raw, fl_raw = rel_l2(raw.cpu(), o_raw), rel_l2(f_raw, o_raw)
     e_pr, fl_pr = rel_l2(pr.float().cpu().permute(0, 3, 1, 2), protos), rel_l2(f_protos, protos)
     print(f"v9c forward: raw rel-L2 {e_raw:.2e} (format floor {fl_raw:.2e})  protos rel-L2 {e_pr:.2e} (floor {fl_pr:.2e})")
-    assert e_raw <= 1.5 * fl_raw + 2e-3 and e_pr <= 1.5 * fl_pr + 2e-3
+    assert fl_raw <= 2e-2, fl_raw                                            # the floor itself must be tight for the bound to mean something
+    assert e_raw <= 1.5 * fl_raw and e_pr <= 1.5 * fl_pr + 2e-3
     eng.backward(R1.to(cuda_device), R2.permute(0, 2, 3, 1).contiguous().to(cuda_device))
     torch.cuda.synchronize()
     names = {n for n, _, _ in eng.trainable()}
