@@ -86,6 +86,10 @@ SIGNATURES = {
                                   C.c_int, _P, _P, C.c_int, C.c_int, _P]),
     "m355_c2f_c32_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int, _P, _P]),
     "m355_bneck_pair_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, C.c_int, _P, C.c_int, _P]),
+    "m355_s2c64_cv1_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P]),
+    "m355_stem_s2c32_cv1_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int, _P]),
+    "m355_proto_phase_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "m355_head_tail_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, _P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, _P]),
     "m355_conv2d_dgrad": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_conv2d_wgrad": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "m355_bn_silu_train_fwd": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, C.c_float, C.c_int, _P, _P, _P, _P, _P]),

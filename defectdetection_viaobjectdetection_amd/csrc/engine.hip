@@ -1118,6 +1118,58 @@ std::vector<std::pair<int, int>> frag_list(int k, int cin, int cout) {
   return f;
 }
 
+// ConvTranspose2d(2x2, s2, bias) followed by Conv3x3 (no activation between them) as four 2x2 phase convs over the low-resolution input
+// (see build_segment_head): fp16 rows [4 n (padded to cout_pad)][Kpad], K = (a * 2 + b) * n + cin, and the [9 border classes][n] bias table.
+void compose_proto_phases(int n, const float* wtp, const float* btp, const float* w3p, const float* b3p, int cout_pad, int Kpad,
+                          std::vector<half_t>& rows, std::vector<float>& btab) {
+    // Weff[q][co][(a*2+b)*n + ci] = sum over the (kh, kw) of phase q = py*2+px that fall on low-res offset (a, b):
+    //   t = py + kh - 1, low-res row offset floor(t / 2) = a - 1 + py, dy = t mod 2 (same for columns)
+    //   Weff += sum_c W3[co, c, kh, kw] * Wt[ci, c, dy, dx]
+    rows.assign((size_t)cout_pad * Kpad, (half_t)0.f);
+    std::vector<double> acc((size_t)n * n);
+    for (int py = 0; py < 2; ++py)
+      for (int px = 0; px < 2; ++px)
+        for (int aa = 0; aa < 2; ++aa)
+          for (int bb = 0; bb < 2; ++bb) {
+            std::fill(acc.begin(), acc.end(), 0.0);
+            for (int kh = 0; kh < 3; ++kh) {
+              const int ty = py + kh - 1, ry = (ty < 0 ? -1 : ty / 2), dy = ty & 1;
+              if (ry + 1 - py != aa) continue;
+              for (int kw = 0; kw < 3; ++kw) {
+                const int tx = px + kw - 1, rx = (tx < 0 ? -1 : tx / 2), dx = tx & 1;
+                if (rx + 1 - px != bb) continue;
+                for (int co = 0; co < n; ++co)
+                  for (int c = 0; c < n; ++c) {
+                    const double w3 = w3p[(((size_t)co * n + c) * 3 + kh) * 3 + kw];
+                    if (w3 == 0.0) continue;
+                    const float* wt = wtp;
+                    double* ar = &acc[(size_t)co * n];
+                    for (int cin = 0; cin < n; ++cin) ar[cin] += w3 * wt[(((size_t)cin * n + c) * 2 + dy) * 2 + dx];
+                  }
+              }
+            }
+            const int q = py * 2 + px;
+            for (int co = 0; co < n; ++co)
+              for (int cin = 0; cin < n; ++cin)
+                rows[(size_t)(q * n + co) * Kpad + (aa * 2 + bb) * n + cin] = (half_t)(float)acc[(size_t)co * n + cin];
+          }
+    // bias table [ry*3+rx][co]: b3 + sum over the taps of the 3x3 window that lie inside the hi-res image of W3 . bt
+    btab.assign((size_t)9 * n, 0.f);
+    for (int ry = 0; ry < 3; ++ry)
+      for (int rx = 0; rx < 3; ++rx)
+        for (int co = 0; co < n; ++co) {
+          double sacc = b3p[co];
+          for (int kh = 0; kh < 3; ++kh) {
+            if ((ry == 0 && kh == 0) || (ry == 2 && kh == 2)) continue;
+            for (int kw = 0; kw < 3; ++kw) {
+              if ((rx == 0 && kw == 0) || (rx == 2 && kw == 2)) continue;
+              for (int c = 0; c < n; ++c) sacc += (double)w3p[(((size_t)co * n + c) * 3 + kh) * 3 + kw] * btp[c];
+            }
+          }
+          btab[(size_t)(ry * 3 + rx) * n + co] = (float)sacc;
+        }
+}
+
 // Fragment order of the row-slab 3x3 kernels (conv3x3_planes.hip): [channel block cb][input plane p][tap][K slice s], plain row
 // permutation -- the K-loop order of one wave, so that its weight stream is one linearly advancing pointer (2 KiB per step).
 std::vector<half_t> planes_frag_pack(const half_t* rows, int Kpad, int cin, int cblocks) {
@@ -1268,52 +1320,9 @@ int m355_set_conv_weights(m355_engine* e, int idx, const float* w, const float* 
     }
     e->conv_loaded[idx] = true;
     if (p.h_wt.empty() || p.h_w3.empty()) return M355_OK;
-    // Weff[q][co][(a*2+b)*n + ci] = sum over the (kh, kw) of phase q = py*2+px that fall on low-res offset (a, b):
-    //   t = py + kh - 1, low-res row offset floor(t / 2) = a - 1 + py, dy = t mod 2 (same for columns)
-    //   Weff += sum_c W3[co, c, kh, kw] * Wt[ci, c, dy, dx]
-    std::vector<half_t> rows((size_t)p.cout_pad * p.Kpad, (half_t)0.f);
-    std::vector<double> acc((size_t)n * n);
-    for (int py = 0; py < 2; ++py)
-      for (int px = 0; px < 2; ++px)
-        for (int aa = 0; aa < 2; ++aa)
-          for (int bb = 0; bb < 2; ++bb) {
-            std::fill(acc.begin(), acc.end(), 0.0);
-            for (int kh = 0; kh < 3; ++kh) {
-              const int ty = py + kh - 1, ry = (ty < 0 ? -1 : ty / 2), dy = ty & 1;
-              if (ry + 1 - py != aa) continue;
-              for (int kw = 0; kw < 3; ++kw) {
-                const int tx = px + kw - 1, rx = (tx < 0 ? -1 : tx / 2), dx = tx & 1;
-                if (rx + 1 - px != bb) continue;
-                for (int co = 0; co < n; ++co)
-                  for (int c = 0; c < n; ++c) {
-                    const double w3 = p.h_w3[(((size_t)co * n + c) * 3 + kh) * 3 + kw];
-                    if (w3 == 0.0) continue;
-                    const float* wt = &p.h_wt[(size_t)0];
-                    double* ar = &acc[(size_t)co * n];
-                    for (int cin = 0; cin < n; ++cin) ar[cin] += w3 * wt[(((size_t)cin * n + c) * 2 + dy) * 2 + dx];
-                  }
-              }
-            }
-            const int q = py * 2 + px;
-            for (int co = 0; co < n; ++co)
-              for (int cin = 0; cin < n; ++cin)
-                rows[(size_t)(q * n + co) * p.Kpad + (aa * 2 + bb) * n + cin] = (half_t)(float)acc[(size_t)co * n + cin];
-          }
-    // bias table [ry*3+rx][co]: b3 + sum over the taps of the 3x3 window that lie inside the hi-res image of W3 . bt
-    std::vector<float> btab((size_t)9 * n);
-    for (int ry = 0; ry < 3; ++ry)
-      for (int rx = 0; rx < 3; ++rx)
-        for (int co = 0; co < n; ++co) {
-          double sacc = p.h_b3[co];
-          for (int kh = 0; kh < 3; ++kh) {
-            if ((ry == 0 && kh == 0) || (ry == 2 && kh == 2)) continue;
-            for (int kw = 0; kw < 3; ++kw) {
-              if ((rx == 0 && kw == 0) || (rx == 2 && kw == 2)) continue;
-              for (int c = 0; c < n; ++c) sacc += (double)p.h_w3[(((size_t)co * n + c) * 3 + kh) * 3 + kw] * p.h_bt[c];
-            }
-          }
-          btab[(size_t)(ry * 3 + rx) * n + co] = (float)sacc;
-        }
+    std::vector<half_t> rows;
+    std::vector<float> btab;
+    compose_proto_phases(n, p.h_wt.data(), p.h_bt.data(), p.h_w3.data(), p.h_b3.data(), p.cout_pad, p.Kpad, rows, btab);
     HIP_TRY(e, hipMemcpy(p.w, rows.data(), rows.size() * sizeof(half_t), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(p.bias, btab.data(), btab.size() * sizeof(float), hipMemcpyHostToDevice));
     if (n == 128) {   // fragment-ordered copy [phase][channel block][32 slices] for proto_phase_wreg.hip
@@ -2043,6 +2052,159 @@ int m355_bneck_pair_fwd(const void* d_x, int B, int H, int W, int C, int ldx, co
   if (rc != 0) return set_err(M355_ERR_HIP, "bneck_pair launch failed: " + std::to_string(rc));
   if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string("bneck_pair kernel: ") + hipGetErrorString(se));
   return M355_OK;
+}
+
+// ---- per-op parity entries of the round-3 fused launches (each: host weights packed exactly as m355_set_conv_weights packs them,
+// one launch, stream synchronised) ---------------------------------------------------------------------------------------------
+}  // extern "C" (C++ helpers follow)
+namespace {
+struct DevBuf {   // device allocations of one entry call, freed on scope exit
+  std::vector<void*> p;
+  ~DevBuf() { for (void* q : p) (void)hipFree(q); }
+  template <class T>
+  T* put(const std::vector<T>& h) {
+    void* d = nullptr;
+    if (hipMalloc(&d, h.size() * sizeof(T) + 16) != hipSuccess) return nullptr;
+    p.push_back(d);
+    if (hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    return (T*)d;
+  }
+  void* raw(size_t bytes) {
+    void* d = nullptr;
+    if (hipMalloc(&d, bytes + 16) != hipSuccess) return nullptr;
+    p.push_back(d);
+    (void)hipMemset(d, 0, bytes + 16);
+    return d;
+  }
+};
+std::vector<half_t> to_half_vec(const float* w, size_t n) {
+  std::vector<half_t> r(n);
+  for (size_t i = 0; i < n; ++i) r[i] = (half_t)w[i];
+  return r;
+}
+int finish_entry(int rc, hipStream_t s, const char* what) {
+  const hipError_t se = hipStreamSynchronize(s);
+  if (rc != 0) return set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, std::string(what) + ": launch refused / failed (" + std::to_string(rc) + ")");
+  if (se != hipSuccess) return set_err(M355_ERR_HIP, std::string(what) + " kernel: " + hipGetErrorString(se));
+  return M355_OK;
+}
+}  // namespace
+extern "C" {
+
+int m355_s2c64_cv1_fwd(const void* d_x, int B, int H, int W, const float* h_w3, const float* h_b3, const float* h_w1, const float* h_b1,
+                       void* d_y, void* stream) {
+  if (!d_x || !d_y || !h_w3 || !h_b3 || !h_w1 || !h_b1 || B < 1 || H < 2 || W < 2) return set_err(M355_ERR_INVALID, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int kp = conv_kpad(64, 3);
+  std::vector<half_t> rows((size_t)conv_cout_pad(128) * kp, (half_t)0.f);
+  pack_conv_rows(h_w3, 128, 64, 3, kp, 0, rows);
+  const std::vector<half_t> r2 = to_half_vec(h_w1, (size_t)128 * 128);
+  std::vector<std::pair<int, int>> fl2;
+  for (int m = 0; m < 4; ++m)
+    for (int sl = 0; sl < 8; ++sl) fl2.push_back({32 * m, 16 * sl});
+  DevBuf d;
+  ConvArgs a{};
+  a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * 64; a.ldx = 64; a.Hi = H; a.Wi = W; a.Cin = 64;
+  a.w = d.put(rows); a.Kpad = kp; a.wf = d.put(frag_pack(rows.data(), kp, frag_list(3, 64, 128), false));
+  a.w2 = d.put(r2); a.wf2 = d.put(frag_pack(r2.data(), 128, fl2, false));
+  std::vector<float> b3(conv_cout_pad(128), 0.f), b1(128);
+  for (int i = 0; i < 128; ++i) { b3[i] = h_b3[i]; b1[i] = h_b1[i]; }
+  a.bias = d.put(b3); a.bias2 = d.put(b1); a.cout2 = 128; a.zero = (const half_t*)d.raw(256);
+  a.ksize = 3; a.stride = 2; a.pad = 1; a.Ho = H / 2; a.Wo = W / 2; a.Cout = 128; a.act = 1; a.w_rows = conv_cout_pad(128);
+  a.y = d_y; a.y_bstride = (long)a.Ho * a.Wo * 128; a.ldy = 128; a.M = B * a.Ho * a.Wo;
+  if (!a.w || !a.wf || !a.w2 || !a.wf2 || !a.bias || !a.bias2 || !a.zero) return set_err(M355_ERR_HIP, "allocation failed");
+  return finish_entry(conv_s2c64_cv1_ok(a) ? launch_conv_s2c64_cv1(a, s) : -1, s, "conv3x3_s2c64 + 1x1");
+}
+
+int m355_stem_s2c32_cv1_fwd(const void* d_in_u8, int B, int H, int W, const float* h_w0, const float* h_b0, const float* h_w1,
+                            const float* h_b1, const float* h_w2, const float* h_b2, void* d_y, int two_team, void* stream) {
+  if (!d_in_u8 || !d_y || !h_w0 || !h_b0 || !h_w1 || !h_b1 || !h_w2 || !h_b2 || B < 1 || H < 4 || W < 4) return set_err(M355_ERR_INVALID, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<half_t> sw((size_t)32 * 32, (half_t)0.f);
+  for (int co = 0; co < 32; ++co)
+    for (int c = 0; c < 3; ++c)
+      for (int kh = 0; kh < 3; ++kh)
+        for (int kw = 0; kw < 3; ++kw) sw[(size_t)co * 32 + (kh * 3 + kw) * 3 + c] = (half_t)h_w0[((co * 3 + c) * 3 + kh) * 3 + kw];
+  const int kp = conv_kpad(32, 3);
+  std::vector<half_t> rows((size_t)conv_cout_pad(64) * kp, (half_t)0.f);
+  pack_conv_rows(h_w1, 64, 32, 3, kp, 0, rows);
+  const std::vector<half_t> r2 = to_half_vec(h_w2, (size_t)64 * 64);
+  std::vector<std::pair<int, int>> fl2;
+  for (int m = 0; m < 2; ++m)
+    for (int sl = 0; sl < 4; ++sl) fl2.push_back({32 * m, 16 * sl});
+  DevBuf d;
+  StemArgs st{};
+  st.x = (const uint8_t*)d_in_u8; st.B = B; st.H = H; st.W = W; st.w16 = d.put(sw);
+  st.bias = d.put(std::vector<float>(h_b0, h_b0 + 32));
+  st.y = (half_t*)d.raw((size_t)B * (H / 2) * (W / 2) * 32 * 2); st.y_bstride = (long)(H / 2) * (W / 2) * 32; st.ldy = 32; st.Cout = 32;
+  ConvArgs a{};
+  a.x = st.y; a.x_bstride = st.y_bstride; a.ldx = 32; a.Hi = H / 2; a.Wi = W / 2; a.Cin = 32;
+  a.w = d.put(rows); a.Kpad = kp; a.wf = d.put(frag_pack(rows.data(), kp, frag_list(3, 32, 64), true));
+  a.w2 = d.put(r2); a.wf2 = d.put(frag_pack(r2.data(), 64, fl2, false));
+  std::vector<float> b1(conv_cout_pad(64), 0.f);
+  for (int i = 0; i < 64; ++i) b1[i] = h_b1[i];
+  a.bias = d.put(b1); a.bias2 = d.put(std::vector<float>(h_b2, h_b2 + 64)); a.cout2 = 64; a.zero = (const half_t*)d.raw(256);
+  a.ksize = 3; a.stride = 2; a.pad = 1; a.Ho = H / 4; a.Wo = W / 4; a.Cout = 64; a.act = 1; a.w_rows = conv_cout_pad(64);
+  a.y = d_y; a.y_bstride = (long)a.Ho * a.Wo * 64; a.ldy = 64; a.M = B * a.Ho * a.Wo;
+  if (!st.w16 || !st.bias || !st.y || !a.w || !a.wf || !a.w2 || !a.wf2 || !a.bias || !a.bias2 || !a.zero) return set_err(M355_ERR_HIP, "allocation failed");
+  int rc = -1;
+  if (two_team) rc = stem_s2c32_v2_ok(a, st) ? launch_stem_s2c32_v2(a, st, s) : -1;
+  else rc = stem_s2c32_ok(a, st) ? launch_stem_s2c32(a, st, s) : -1;
+  return finish_entry(rc, s, "stem + conv3x3_s2c32 + 1x1");
+}
+
+int m355_proto_phase_fwd(const void* d_x, int B, int H, int W, const float* h_wt, const float* h_bt, const float* h_w3, const float* h_b3,
+                         const float* h_wc, const float* h_bc, void* d_y, void* stream) {
+  if (!d_x || !d_y || !h_wt || !h_bt || !h_w3 || !h_b3 || !h_wc || !h_bc || B < 1) return set_err(M355_ERR_INVALID, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int n = 128, kp = conv_kpad(4 * n, 1), cp = conv_cout_pad(4 * n);
+  std::vector<half_t> rows;
+  std::vector<float> btab;
+  compose_proto_phases(n, h_wt, h_bt, h_w3, h_b3, cp, kp, rows, btab);
+  std::vector<std::pair<int, int>> fl, fl2;
+  for (int q = 0; q < 4; ++q)
+    for (int mb = 0; mb < 4; ++mb)
+      for (int sl = 0; sl < 32; ++sl) fl.push_back({q * 128 + 32 * mb, 16 * sl});
+  for (int sl = 0; sl < 8; ++sl) fl2.push_back({0, 16 * sl});
+  const std::vector<half_t> r2 = to_half_vec(h_wc, (size_t)32 * 128);
+  DevBuf d;
+  ConvArgs a{};
+  a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * n; a.ldx = n; a.Hi = H; a.Wi = W; a.Cin = n;
+  a.w = d.put(rows); a.Kpad = kp; a.bias = d.put(btab); a.wf = d.put(frag_pack(rows.data(), kp, fl, false));
+  a.w2 = d.put(r2); a.wf2 = d.put(frag_pack(r2.data(), 128, fl2, false)); a.bias2 = d.put(std::vector<float>(h_bc, h_bc + 32)); a.cout2 = 32;
+  a.zero = (const half_t*)d.raw(256); a.act = 1; a.ksize = 2; a.stride = 1; a.pad = 0; a.phase = 1;
+  a.Ho = H; a.Wo = W; a.Cout = 4 * n; a.convt_co = n; a.w_rows = cp;
+  a.y = d_y; a.y_bstride = (long)4 * H * W * 32; a.ldy = 32; a.M = B * H * W;
+  if (!a.w || !a.wf || !a.w2 || !a.wf2 || !a.bias || !a.bias2 || !a.zero) return set_err(M355_ERR_HIP, "allocation failed");
+  return finish_entry(proto_phase_wreg_ok(a) ? launch_proto_phase_wreg(a, s) : -1, s, "proto_phase_wreg");
+}
+
+int m355_head_tail_fwd(const void* d_x, int B, int H, int W, int nc, float stride, const float* h_w2, const float* h_b2, const float* h_w3,
+                       const float* h_b3, const float* h_w4, const float* h_b4, float* d_preds, int A, int level_off, void* stream) {
+  if (!d_x || !d_preds || !h_w2 || !h_b2 || !h_w3 || !h_b3 || !h_w4 || !h_b4 || B < 1 || nc < 1 || nc > 32) return set_err(M355_ERR_INVALID, "bad argument");
+  hipStream_t s = (hipStream_t)stream;
+  const int cout = 64 + nc + 32, kp = conv_kpad(224, 1), rows_pad = conv_cout_pad(cout);
+  std::vector<half_t> rows((size_t)rows_pad * kp, (half_t)0.f);
+  pack_conv_rows(h_w2, 64, 64, 1, kp, 0, rows, 0);           // box rows over K 0 .. 63
+  pack_conv_rows(h_w3, nc, 128, 1, kp, 64, rows, 64);        // class rows over K 64 .. 191
+  pack_conv_rows(h_w4, 32, 32, 1, kp, 64 + nc, rows, 192);   // coefficient rows over K 192 .. 223
+  std::vector<std::pair<int, int>> fl;
+  for (int blk = 0; blk < 2; ++blk)
+    for (int sl = 0; sl < 4; ++sl) fl.push_back({32 * blk, 16 * sl});
+  for (int sl = 0; sl < 8; ++sl) fl.push_back({64, 64 + 16 * sl});
+  for (int sl = 0; sl < 2; ++sl) fl.push_back({64 + nc, 192 + 16 * sl});
+  if (64 + nc + 32 > rows_pad) return set_err(M355_ERR_INVALID, "row padding");
+  std::vector<float> bias(rows_pad, 0.f);
+  for (int i = 0; i < 64; ++i) bias[i] = h_b2[i];
+  for (int i = 0; i < nc; ++i) bias[64 + i] = h_b3[i];
+  for (int i = 0; i < 32; ++i) bias[64 + nc + i] = h_b4[i];
+  DevBuf d;
+  HeadTailArgs ha{};
+  ha.x = (const half_t*)d_x; ha.ldx = 224; ha.M = (long)B * H * W; ha.HW = H * W; ha.W = W; ha.stride = stride;
+  ha.A = A; ha.level_off = level_off; ha.nc = nc; ha.nm = 32;
+  ha.wf = d.put(frag_pack(rows.data(), kp, fl, false)); ha.bias = d.put(bias); ha.preds = d_preds;
+  if (!ha.wf || !ha.bias) return set_err(M355_ERR_HIP, "allocation failed");
+  return finish_entry(head_tail_ok(ha) ? launch_head_tail(ha, s) : -1, s, "head_tail");
 }
 
 int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const float* h_w, int cout, int k, int stride,

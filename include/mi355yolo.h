@@ -149,6 +149,28 @@ int m355_c2f_c32_fwd(const void* d_x_f16_nhwc, int B, int H, int W, const float*
  * (M355_ERR_INVALID).  [sync] */
 int m355_bneck_pair_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int C, int ldx, const float* h_wa, const float* h_ba,
                         const float* h_wb, const float* h_bb, int shortcut, void* d_y_f16_nhwc, int ldy, void* stream);
+/* Per-op parity entries of the fused launches (round 3 kernels; host weights fp32 with BN folded, packed + uploaded here exactly as
+ * m355_set_conv_weights packs them; a shape the kernel does not take is refused with M355_ERR_INVALID).  [sync]
+ *   m355_s2c64_cv1_fwd       csrc/conv3x3_s2c64.hip: Conv3x3/s2 (64 -> 128) + SiLU -> fp16 -> Conv1x1 (128 -> 128) + SiLU; upstream
+ *                            model.3 + model.4.cv1 of yolov8s.  d_x (B,H,W,64) -> d_y (B,H/2,W/2,128); H/2 and W/2 multiples of 8.
+ *   m355_stem_s2c32_cv1_fwd  csrc/conv_stem_c2.hip (two_team = 1) / conv_stem_s2c32.hip (0): uint8 image -> Conv3x3/s2 (3 -> 32, the
+ *                            1/255 input scale inside) -> Conv3x3/s2 (32 -> 64) -> Conv1x1 (64 -> 64), SiLU + fp16 after each; upstream
+ *                            model.0 + model.1 + model.2.cv1.  d_in (B,H,W,3) uint8 -> d_y (B,H/4,W/4,64); H/4 % 8 == 0, W/4 % 16 == 0.
+ *   m355_proto_phase_fwd     csrc/proto_phase_wreg.hip: Proto.upsample (ConvTranspose2d 2x2/s2, bias; weight (cin,cout,2,2)) -> Proto.cv2
+ *                            (3x3 + SiLU) -> Proto.cv3 (1x1, 128 -> 32, + SiLU) composed into four 2x2 phase convs.  d_x (B,H,W,128) ->
+ *                            d_y (B,2H,2W,32); H % 8 == 0, W % 16 == 0.
+ *   m355_head_tail_fwd       csrc/head_tail.hip: the three output convs of one Detect / Segment level (cv2.l.2 64 -> 64 box bins,
+ *                            cv3.l.2 128 -> nc, cv4.l.2 32 -> 32, with bias) + DFL + dist2bbox + sigmoid: d_x (B,H,W,224) = [box 64 |
+ *                            class 128 | coefficient 32] branch tensor -> rows [level_off, level_off + H W) of d_preds (B,A,4+nc+32) fp32. */
+int m355_s2c64_cv1_fwd(const void* d_x_f16_nhwc, int B, int H, int W, const float* h_w3, const float* h_b3, const float* h_w1,
+                       const float* h_b1, void* d_y_f16_nhwc, void* stream);
+int m355_stem_s2c32_cv1_fwd(const void* d_in_u8_nhwc, int B, int H, int W, const float* h_w0, const float* h_b0, const float* h_w1,
+                            const float* h_b1, const float* h_w2, const float* h_b2, void* d_y_f16_nhwc, int two_team, void* stream);
+int m355_proto_phase_fwd(const void* d_x_f16_nhwc, int B, int H, int W, const float* h_wt, const float* h_bt, const float* h_w3,
+                         const float* h_b3, const float* h_wc, const float* h_bc, void* d_y_f16_nhwc, void* stream);
+int m355_head_tail_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int nc, float stride, const float* h_w2, const float* h_b2,
+                       const float* h_w3, const float* h_b3, const float* h_w4, const float* h_b4, float* d_preds, int A, int level_off,
+                       void* stream);
 /* Data gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2, no bias) (SURVEY A13 backward): dY fp16 NHWC
  * (B,Ho,Wo,cout) -> dX fp16 NHWC (B,H,W,cin).  Runs on the same implicit-GEMM kernel: stride 1 = convolution
  * with the spatially flipped, channel-transposed weights; stride 2 = transposed-stride gather.  h_w is the
