@@ -70,7 +70,7 @@ struct ConvArgs {
   // them): [0] tiles claimed beyond each block's static first one, [1] blocks that have left.  nullptr: static walk.
   // One queue per op -- never shared by launches that can run at the same time.
   int* tileq;
-  // Fragment-ordered copy of `w` for the weights-in-registers kernels (conv3x3_c64r / conv3x3_c128r / conv1x1_wreg): fragment
+  // Fragment-ordered copy of `w` for the weights-in-registers kernels (conv1x1_wreg, conv3x3_s2c64, ...): fragment
   // f at halves [f * 512, f * 512 + 512), lane-linear 16 bytes = the A operand of one 32x32x16 MFMA.  nullptr: the kernels
   // gather the fragments from `w` (64 scattered 16-byte loads per fragment).
   const half_t* wf;
@@ -79,7 +79,7 @@ struct ConvArgs {
 };
 
 // tile ids for launch_conv_igemm(force_tile)
-enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_SLAB = 25, TILE_M32 = 26, TILE_M32_128 = 27, TILE_M32_64x16 = 28, TILE_M32_64x8 = 29, TILE_C64R = 30, TILE_C128R = 31, TILE_W1 = 32, TILE_PLANES = 33 };
+enum { TILE_AUTO = -1, TILE_128x128 = 0, TILE_64x128 = 1, TILE_32x256 = 2, TILE_64x256 = 3, TILE_64x128W8 = 5, TILE_HALO = 16, TILE_HALO8W = 17, TILE_HALO4W = 18, TILE_HALOWIDE = 19, TILE_C32 = 20, TILE_SLAB = 25, TILE_M32 = 26, TILE_M32_128 = 27, TILE_M32_64x16 = 28, TILE_M32_64x8 = 29, TILE_W1 = 32, TILE_PLANES = 33 };
 
 // Experiment switches (environment variables M355_*), read once per process: launchers are on the hot path.
 struct Knobs {
@@ -123,12 +123,6 @@ int launch_msda(const float* value, const float* loc, const float* attn, float* 
                 const float* ref = nullptr, float offset_scale = 0.f);
 int launch_dfine_decode(const float* dist, const float* project, const float* ref, float* boxes, long n, int nbins1,
                         float reg_scale, int clamp01, hipStream_t s);
-// Cin = Cout = 64, weights in registers, persistent (conv3x3_c64r.hip)
-bool conv3x3_c64r_ok(const ConvArgs& a);
-int launch_conv3x3_c64r(const ConvArgs& a, hipStream_t s);
-// Cin = Cout = 128, weights in registers, K split over the two waves of a SIMD, 8 x 8 tiles (conv3x3_c128r.hip)
-bool conv3x3_c128r_ok(const ConvArgs& a);
-int launch_conv3x3_c128r(const ConvArgs& a, hipStream_t s);
 // 1x1, K <= 512, Cout % 128 == 0: weights in registers, persistent (conv1x1_wreg.hip)
 bool conv1x1_wreg_ok(const ConvArgs& a);
 int launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s);

@@ -880,8 +880,6 @@ bool conv_forced_tile_extent(int tile, int cout, int* bch, int* bpx) {
     case TILE_HALOWIDE: c = 128; p = 256; break;
     case TILE_SLAB: c = 64; p = 256; break;
     case TILE_C32: c = 32; p = 256; break;
-    case TILE_C64R: c = 64; p = 128; break;
-    case TILE_C128R: c = 128; p = 64; break;
     case TILE_W1: c = 128; p = 64; break;
     case TILE_PLANES: c = 64; p = 256; break;
     case TILE_M32: c = cout > 64 ? 128 : 64; p = 256; break;

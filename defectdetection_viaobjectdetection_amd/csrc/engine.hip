@@ -91,8 +91,8 @@ struct PhysConv {
   half_t* w = nullptr;
   float* bias = nullptr;
   float* stem_w = nullptr;  // stem only: [27][cout] fp32
-  // fragment-ordered copies of `w` for the weights-in-registers kernels (frag_pack below): wf = plain row order (conv3x3_c64r /
-  // conv3x3_c128r / conv1x1_wreg / c2f_c32's first conv), wf2 = operand row order (c2f_c32's second conv); nullptr = not built
+  // fragment-ordered copies of `w` for the weights-in-registers kernels (frag_pack below): wf = plain row order (conv1x1_wreg,
+  // conv3x3_s2c64, c2f_c32's first conv, the row-slab kernels), wf2 = operand row order (c2f_c32's second conv); nullptr = not built
   half_t* wf = nullptr;
   half_t* wf2 = nullptr;
   int planes = 0;            // wf = the K-loop fragment order of the row-slab 3x3 kernels (planes_frag_pack)
@@ -883,14 +883,9 @@ void annotate_ops(m355_engine* e) {
           m32 = op.tile == TILE_HALO && !wide && !getenv("M355_NO_M32") && conv3x3_m32_ok(probe) && (cout_v > 64 || ti.H * ti.W <= 1600);
           probe.ldx = 8;
           if (op.kind == OP_CONV && conv3x3_c32_ok(probe) && !getenv("M355_NO_C32")) op.tile = TILE_C32;
-          {   // 64 -> 64 on maps the 8 x 16 tiles cover exactly: weights in registers (conv3x3_c64r.hip)
+          {
             ConvArgs pr2 = probe;
             pr2.ldx = ti.C; pr2.ldy = 8; pr2.Kpad = p.Kpad; pr2.M = e->desc.max_batch * Ho * Wo; pr2.x_bstride = (long)ti.H * ti.W * ti.C;
-            // OPT-IN (M355_C64R=1): measured 27.5 us per layer against 28 on the halo kernel -- no gain
-            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && conv3x3_c64r_ok(pr2) && getenv("M355_C64R")) {
-              op.tile = TILE_C64R;
-              wide = m32 = false;
-            }
             // 1x1 with K <= 512 and Cout a multiple of 128: weights in registers (conv1x1_wreg.hip)
             if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !p.diag && op.in2.t < 0 && op.res.t < 0 && !op.decode) {
               ConvArgs pr3 = pr2;
@@ -898,14 +893,8 @@ void annotate_ops(m355_engine* e) {
               pr3.ldy = to2.C; pr3.y_bstride = (long)to2.H * to2.W * to2.C;
               if (conv1x1_wreg_ok(pr3) && !getenv("M355_NO_W1")) op.tile = TILE_W1;
             }
-            // 128 -> 128 on maps the wide kernel's 16 x 16 tiles do not fit (40 x 40): K split over wave pairs (conv3x3_c128r.hip).
-            // OPT-IN (M355_C128R=1): measured 31 us per layer against 25-27 on the 32x32x16 halo kernel
-            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !wide && conv3x3_c128r_ok(pr2) && getenv("M355_C128R")) {
-              op.tile = TILE_C128R;
-              m32 = false;
-            }
           }
-          if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && op.tile != TILE_C64R && op.tile != TILE_C128R && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
+          if (op.kind == OP_CONV && op.tile != TILE_HALO && op.tile != TILE_C32 && conv3x3_slab_ok(probe) && !getenv("M355_NO_SLAB"))
             op.tile = TILE_SLAB;
         }
         // row-slab kernel in single-conv mode (conv3x3_planes.hip) for what the slab kernel took (the 20 x 20 level): one block per CU
@@ -925,10 +914,6 @@ void annotate_ops(m355_engine* e) {
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_planes<64ch,rows>");
         else if (op.tile == TILE_W1)
           snprintf(op.kernel, sizeof(op.kernel), "conv1x1_wreg<K%d,%dch>", p.cin, cout_v % 256 == 0 ? 256 : 128);
-        else if (op.tile == TILE_C128R)
-          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c128r<128ch,8x8px>");
-        else if (op.tile == TILE_C64R)
-          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c64r<64ch,8x16px>");
         else if (op.tile == TILE_C32)
           snprintf(op.kernel, sizeof(op.kernel), "conv3x3_c32<32ch,16x16px>");
         else if (op.tile == TILE_SLAB)
@@ -1075,8 +1060,7 @@ void pack_conv_rows(const float* w, int cout, int cin, int k, int Kpad, int row0
 // Fragment-ordered copy of packed rows for the weights-in-registers kernels.  Fragment f = (first row r0 of a 32-row block,
 // first K element k0 of a 16-deep slice); out[(f * 64 + lane) * 8 + j] = rows[(r0 + perm(lane & 31)) * Kpad + k0 + 8 * (lane >> 5)
 // + j]: exactly the A operand of one v_mfma_f32_32x32x16_f16, so a wave fetches a fragment with ONE coalesced 1 KiB load
-// (lane-linear 16 bytes) instead of 64 scattered 16-byte pieces of 32 different rows (measured: the scattered prologue of
-// conv3x3_c64r cost ~10 us of a 31 us launch).  perm: plain (lane-half h's accumulators = channels 16 h + r) or operand
+// (lane-linear 16 bytes) instead of 64 scattered 16-byte pieces of 32 different rows (measured in round 3: a scattered prologue cost ~10 us of a 31 us launch).  perm: plain (lane-half h's accumulators = channels 16 h + r) or operand
 // (c2f_c32.hip: accumulators = the next MFMA's B fragments).
 int frag_row(int rho, bool operand) {
   if (!operand) return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3);
@@ -1095,15 +1079,9 @@ std::vector<half_t> frag_pack(const half_t* rows, int Kpad, const std::vector<st
 // the fragment lists of the kernels, by conv shape (empty = none of them takes this conv)
 std::vector<std::pair<int, int>> frag_list(int k, int cin, int cout) {
   std::vector<std::pair<int, int>> f;
-  if (k == 3 && cin == 64 && cout == 64) {                      // conv3x3_c64r: [channel block m][36 slices]
-    for (int m = 0; m < 2; ++m)
-      for (int s = 0; s < 36; ++s) f.push_back({32 * m, 16 * s});
-  } else if (k == 3 && cin == 128 && cout == 128) {             // conv3x3_c128r: [m][input-channel half][tap][slice]
-    for (int m = 0; m < 4; ++m)
-      for (int kh = 0; kh < 2; ++kh)
-        for (int tap = 0; tap < 9; ++tap)
-          for (int s = 0; s < 4; ++s) f.push_back({32 * m, 128 * tap + 64 * kh + 16 * s});
-  } else if (k == 3 && cin == 64 && cout == 128) {              // conv3x3_s2c64: [channel block m][36 slices]
+  // (64 -> 64 and 128 -> 128 3x3 convs had lists for conv3x3_c64r / conv3x3_c128r: measured no gain in round 3, deleted in round 4;
+  // such a conv gets fragments only when a row-slab launch uses it -- PhysConv::planes, planes_frag_pack)
+  if (k == 3 && cin == 64 && cout == 128) {              // conv3x3_s2c64: [channel block m][36 slices]
     for (int m = 0; m < 4; ++m)
       for (int s = 0; s < 36; ++s) f.push_back({32 * m, 16 * s});
   } else if (k == 3 && cin == 32 && cout == 64) {               // conv_stem_c2 (model.1): [channel block][18 slices], operand row order
@@ -1589,8 +1567,6 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
              : (op.s2c64 && conv_s2c64_cv1_ok(a)) ? launch_conv_s2c64_cv1(a, s)
              : (op.tile == TILE_HALO) ? launch_conv3x3_halo(a, 0, s)
-             : (op.tile == TILE_C64R) ? launch_conv3x3_c64r(a, s)
-             : (op.tile == TILE_C128R) ? launch_conv3x3_c128r(a, s)
              // (the pixel count of THIS call may not be a multiple of the kernel's tile although max_batch's was: im2col then)
              : (op.tile == TILE_W1) ? (conv1x1_wreg_ok(a) ? launch_conv1x1_wreg(a, s) : launch_conv_igemm(a, TILE_AUTO, s))
              : (op.tile == TILE_C32 ? launch_conv3x3_c32(a, s)
@@ -1914,9 +1890,7 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
     }
   } else
   for (int rep = 0; rep < (a.dbg ? 5 : 1); ++rep)
-    rc = (force_tile >= 0 && (force_tile & 0xff) == TILE_C64R) ? launch_conv3x3_c64r(a, s)
-         : (force_tile >= 0 && (force_tile & 0xff) == TILE_C128R) ? launch_conv3x3_c128r(a, s)
-         : (force_tile >= 0 && (force_tile & 0xff) == TILE_W1) ? launch_conv1x1_wreg(a, s)
+    rc = (force_tile >= 0 && (force_tile & 0xff) == TILE_W1) ? launch_conv1x1_wreg(a, s)
          : (force_tile >= 0 && (force_tile & 0xff) == TILE_C32)
              ? launch_conv3x3_c32(a, s)
              : ((force_tile >= 0 && (force_tile & 0xff) >= TILE_HALO) ? launch_conv3x3_halo(a, (force_tile & 0xff) - TILE_HALO, s)

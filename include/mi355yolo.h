@@ -125,6 +125,29 @@ int m355_set_keep_raw(m355_engine* e, int keep);
 int m355_postprocess(m355_engine* e, const float* d_preds, const void* d_protos, int batch, float conf,
                      float iou, int max_det, float* d_dets, int* d_counts, uint8_t* d_masks, void* stream);
 
+/* ---- Environment switches ----------------------------------------------------------------------------------------------------
+ * The library is configured by m355_model_desc and the arguments of each call.  The M355_* environment variables below are
+ * read-once A/B switches for measurements and tests; none is needed in production and none changes the ABI.  Unset = the default
+ * described here.  Switches that change which kernels m355_forward launches (results stay within the parity tolerances; every
+ * pair is A/B-tested in tests/test_c2f_fused_gpu.py / test_engine_gpu.py):
+ *   M355_NO_PAIR        Bottleneck pairs as two launches instead of one bneck_pair launch (conv3x3_planes.hip)
+ *   M355_PAIR64=1       also use the pair launch for 64-channel bottlenecks (measured no gain: off)
+ *   M355_NO_PLANES      the 20 x 20 level on conv3x3_slab instead of the row-slab kernel
+ *   M355_NO_C2F32       model.2 as three launches instead of c2f_c32
+ *   M355_NO_W1, M355_NO_S2C64, M355_NO_S2C32, M355_NO_PROTOR, M355_NO_PROTOFUSE(3), M355_NO_HEADTAIL, M355_NO_STEMFUSE,
+ *   M355_NO_STEM2, M355_NO_CVFUSE, M355_NO_UPFUSE, M355_NO_C32, M355_NO_M32, M355_NO_WIDE, M355_NO_HALO, M355_NO_SLAB,
+ *   M355_DECFUSE=1      each falls back from one fused / specialised kernel to the kernels it replaced (names = file names in csrc/)
+ *   M355_NO_LANES, M355_LANE_PLAN, M355_SUBBATCH(_OPS), M355_NO_SUBBATCH   stream lanes / sub-batches inside a forward
+ * Tuning knobs of single kernels (tile queues, slot counts, priorities): M355_PERSIST, M355_NO_PERSIST, M355_STATIC_TILES,
+ *   M355_M32_SLOTS, M355_C32_SLOTS, M355_C32_WASTE, M355_WIDE_SLOTS, M355_WIDE_STAGGER, M355_HALO_VARIANT, M355_K1_TILE, M355_SMALLM,
+ *   M355_S2C32_RING, M355_S2C64_PRIO, M355_PROTOR_PRIO, M355_C2F_NOPRIO, M355_STEM2_NXB, M355_NO_FAST_EPI, M355_NO_BIAS_LDS,
+ *   M355_STEM_GATHER, M355_MASK_TILE, M355_WGRAD_BLOCKS, M355_WGRAD3_{BLOCKS,MINTILES,SHRINK,SLABMB}, M355_NO_WGRAD3,
+ *   M355_NO_TRAIN_W1, M355_NO_TRAIN_C32.
+ * Diagnostics (write files / print timings, never set in production): M355_STAMPS, M355_*_STAMPS, M355_*_DBG, M355_BNECK_REPS;
+ * testing only: M355_HEADTAIL_MAXM (forces head levels off the head_tail launch).
+ * Python side (train_engine.py, bench.py): M355_NO_WGRAD_STREAM, M355_NO_HEAD_STREAM, M355_SIDE_STREAMS, M355_NO_LOSS_KERNELS,
+ * M355_DIST_BACKEND, M355_DIST_SAME_DEVICE. */
+
 /* ---- per-op entry points for unit parity (all device pointers, asynchronous unless noted) ---- */
 
 /* NHWC fp16 convolution + bias (+SiLU) (+residual) via the implicit-GEMM MFMA kernel.

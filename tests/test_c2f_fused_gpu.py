@@ -120,15 +120,17 @@ def test_engine_with_the_fused_block_equals_the_three_launches(cuda_device):
 @pytest.mark.parametrize("size,batch", [(320, 4), (640, 6)])
 def test_weights_in_registers_kernels_equal_the_im2col_forms(cuda_device, size, batch):
     """The round-3 kernels that keep their weights in registers -- conv1x1_wreg (1x1, K <= 512), conv3x3_s2c64 (model.3 + model.4.cv1), proto_phase_wreg
-    (the composed Proto launch) and, opt-in, conv3x3_c64r / conv3x3_c128r -- against the im2col / halo kernels they replace, whole network,
-    same weights: same rounding points, different fp32 summation order only."""
+    (the composed Proto launch) -- and round 4's row-slab launches (bneck_pair: a whole Bottleneck per launch; conv3x3_planes on the 20 x 20 level) --
+    against the im2col / halo / slab kernels they replace, whole network, same weights: same rounding points, different fp32 summation
+    order only."""
     from defectdetection_viaobjectdetection_amd.engine import SegEngine
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
     from defectdetection_viaobjectdetection_amd.synthetic import synthetic_bscans
     sd = synthetic_state_dict("s", 1, seed=0)
     imgs = torch.from_numpy(synthetic_bscans(batch, size, size, seed=6)).to(cuda_device)
-    variants = {"default": {}, "old": {"M355_NO_W1": "1", "M355_NO_PROTOR": "1", "M355_NO_C2F32": "1", "M355_NO_S2C64": "1"},
-                "all": {"M355_C64R": "1", "M355_C128R": "1"}}
+    variants = {"default": {}, "old": {"M355_NO_W1": "1", "M355_NO_PROTOR": "1", "M355_NO_C2F32": "1", "M355_NO_S2C64": "1", "M355_NO_PAIR": "1",
+                                       "M355_NO_PLANES": "1"},
+                "all": {"M355_PAIR64": "1"}}
     outs, kern = {}, {}
     for name, env in variants.items():
         os.environ.update(env)
@@ -144,12 +146,13 @@ def test_weights_in_registers_kernels_equal_the_im2col_forms(cuda_device, size, 
         outs[name] = (preds.clone(), protos.float().clone())
         eng.close()
     assert any(k.startswith("conv1x1_wreg") for k in kern["default"])
-    assert not any(k.startswith(("conv1x1_wreg", "proto_phase_wreg", "c2f_c32", "conv3x3_s2c64")) for k in kern["old"])
+    assert not any(k.startswith(("conv1x1_wreg", "proto_phase_wreg", "c2f_c32", "conv3x3_s2c64", "bneck_pair", "conv3x3_planes")) for k in kern["old"])
+    assert any(k.startswith("bneck_pair<128ch>") for k in kern["default"]) and any(k.startswith("conv3x3_planes") for k in kern["default"])
+    assert any(k.startswith("bneck_pair<64ch>") for k in kern["all"]) and not any(k.startswith("bneck_pair<64ch>") for k in kern["default"])
     if size == 640:       # (their tiles need 80 x 80 / 40 x 40 maps that are multiples of 8 x 16 / 8 x 8; the conv + cv1 launch
         # exists from 38400 output pixels on: six images)
         assert any(k.startswith("conv3x3_s2c64") for k in kern["default"])
         assert any(k.startswith("proto_phase_wreg") for k in kern["all"])
-        assert any(k.startswith("conv3x3_c64r") for k in kern["all"]) and any(k.startswith("conv3x3_c128r") for k in kern["all"])
     q = lambda t, f: float(t.flatten().kthvalue(max(1, int(t.numel() * f)))[0])
     for name in ("default", "all"):
         dp = (outs[name][0] - outs["old"][0]).abs()

@@ -77,16 +77,6 @@ CONV_CASES = [
     (2, 32, 32, 32, 32, 3, 1, 1, True, 20),         # residual, full tiles
     (3, 72, 56, 32, 32, 3, 1, 1, False, 20),        # partial spatial tiles
     (1, 160, 160, 32, 32, 3, 1, 0, False, 20),      # several tiles per block is exercised by the engine tests; no act
-    # weights-in-registers kernel (30, conv3x3_c64r.hip): Cin = Cout = 64, 8 x 16 tiles, persistent
-    (2, 80, 80, 64, 64, 3, 1, 1, True, 30),         # the C2f layer shape, residual
-    (1, 8, 16, 64, 64, 3, 1, 1, False, 30),         # one tile: all four borders at once
-    (3, 24, 48, 64, 64, 3, 1, 0, True, 30),         # no activation, residual
-    (40, 80, 80, 64, 64, 3, 1, 1, False, 30),       # 2000 tiles over 256 blocks: 7 or 8 tiles per block, the patch pipeline
-    # K split over wave pairs, weights in registers (31, conv3x3_c128r.hip): Cin = Cout = 128, 8 x 8 tiles
-    (2, 40, 40, 128, 128, 3, 1, 1, True, 31),       # the C2f layer shape at 40 x 40, residual
-    (1, 8, 8, 128, 128, 3, 1, 1, False, 31),        # one tile: all four borders at once
-    (3, 24, 16, 128, 128, 3, 1, 0, True, 31),       # no activation, residual
-    (48, 40, 40, 128, 128, 3, 1, 1, False, 31),     # 1200 tiles over 256 blocks: 4 or 5 tiles per block
     # 1x1 with the weights in registers (32, conv1x1_wreg.hip): K <= 512, Cout % 128 == 0, flat pixel axis
     (2, 80, 80, 256, 128, 1, 1, 1, False, 32),      # C2f.cv2 at 80 x 80: 128-pixel tiles, four channel blocks x two pixel halves
     (1, 80, 80, 192, 128, 1, 1, 1, False, 32),      # K = 192: 3-bit chunk swizzle, three tile buffers

@@ -6,7 +6,8 @@ import csv, json, re, sys, collections
 LABELS = {
     "c2f_c32_kernel": "c2f_c32<8x16px>", "proto_phase_wreg_kernel": "proto_phase_wreg<8x16px>",
     "conv3x3_s2c64_cv1_kernel": "conv3x3_s2c64<8x8px>+1x1", "head_tail_kernel": "head_tail<128px>",
-    "conv3x3_c64r_kernel": "conv3x3_c64r<64ch,8x16px>", "conv3x3_c128r_kernel": "conv3x3_c128r<128ch,8x8px>",
+    "PCfg<4, 9, 7, true": "bneck_pair<128ch>", "PCfg<2, 8, 6, true": "bneck_pair<64ch>", "PCfg<2, 0, 4, false": "conv3x3_planes<64ch,rows>",
+    "PCfgILi4ELi9ELi7ELb1": "bneck_pair<128ch>", "PCfgILi2ELi8ELi6ELb1": "bneck_pair<64ch>", "PCfgILi2ELi0ELi4ELb0": "conv3x3_planes<64ch,rows>",
     "conv3x3_halo_kernel<4, 4, 2, 2>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 4>": "conv3x3_halo<64ch>",
     "conv3x3_halo_kernel<4, 4, 2, 4>": "conv3x3_halo<128ch>", "conv3x3_halo_kernel<4, 2, 1, 8>": "conv3x3_halo<64ch>",
     "conv_igemm_kernel<4, 4, 2, 2, 3>": "conv_igemm<128x128,k3>", "conv_igemm_kernel<4, 4, 2, 2, 1>": "conv_igemm<128x128,k1>",
