@@ -173,7 +173,8 @@ int launch_c2f_c32(const C2fC32Args& a, hipStream_t s);
 // K = tap * Cin + 32 p + 16 s .. + 15; 1 KiB each, lane-linear.
 struct PlanesArgs {
   const half_t* x; long x_bstride; int ldx;      // NHWC fp16 input slice (Cin channels)
-  int H, W, B, Cin, Cout;
+  int H, W, B, Cin, Cout;                        // H, W: INPUT map
+  int stride;                                    // 1, or 2 (single mode only: output map H / 2 x W / 2)
   const half_t *wfa, *wfb; int cblocks_a, cblocks_b;   // fragment-ordered weights and their 32-channel blocks; wfa / ba: first conv of a pair (nullptr in single mode)
   const float *ba, *bb;
   half_t* y; long y_bstride; int ldy;

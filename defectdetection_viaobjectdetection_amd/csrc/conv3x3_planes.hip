@@ -60,8 +60,9 @@ struct PlanesGeom {
   int off_x, off_s;         // LDS byte offsets: input ring, one spare KiB behind it (reads of never-stored pixel blocks may run past a slot)
 };
 
-template <int WC_, int NPB1_, int NPB2_, bool PAIR_, int PPS_, int NW_ = 4>
+template <int WC_, int NPB1_, int NPB2_, bool PAIR_, int PPS_, int NW_ = 4, bool S2_ = false>
 struct PCfg {
+  static constexpr bool S2 = S2_;                 // stride 2 (single mode): the input plane is stored as four sub-planes (row parity x column parity)
   static constexpr int NW = NW_;                  // waves per block: 4 (one per SIMD) or 8 (two: the VALU pipe of one beside the MFMAs of the other)
   static constexpr int WC = WC_, WP = NW_ / WC_, NPB1 = NPB1_, NPB2 = NPB2_, PPS = PPS_;
   static constexpr bool PAIR = PAIR_;
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void planes_kernel(const Pla
   const int l31 = lane & 31, h = lane >> 5;
   const int lrow = lane >> 2, lchunk = lane & 3;
   const int wc = wave % C::WC, wp = wave / C::WC;
-  const int H = a.H, W = a.W, PW = g.PW, R = g.R;
+  const int H = a.H, W = a.W, PW = g.PW, R = g.R;   // H, W: input map
+  const int Ho = C::S2 ? H / 2 : H, Wo = C::S2 ? W / 2 : W;   // output map (PW = Wo + 1)
   const int nwg = gridDim.x, ntiles = g.ntiles;
   unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long pst[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // diagnostic: start of phase 0, 1, 2, last of either conv, end
@@ -282,15 +284,30 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void planes_kernel(const Pla
   // input pieces of a tile: piece k = wave + 4 m covers LDS rows 16 k .. 16 k + 15 = storage indices; index j = rj * PW + cj is
   // image pixel (y0 - HALO + rj, cj - 1); outside the image (and the shared zero column cj = 0) the offset fails the range
   // check and the LDS-DMA writes zeros
+  // Stride 2: a plane is FOUR sub-planes (input row parity rp x column parity cp) of (R + 1) x PW storage indices each, so that every
+  // tap reads consecutive indices again: output pixel (yo, xo) at tap (kh, kw) reads sub-plane (kh != 1, kw != 1) at index
+  // q + (kh != 0) * PW + (kw != 0), q = (yo - y0) * PW + xo; sub-plane index rr * PW + cc is input pixel (2 (y0 + rr - 1) + rp,
+  // 2 (cc - 1) + cp).  The de-interleaving happens on the DMA's source side (per-lane addresses).
   constexpr int HALO = C::PAIR ? 2 : 1;
-  const int xrows_valid = (R + 2 * HALO) * PW;
+  const int spr = (R + 1) * PW;                          // storage indices of one sub-plane (stride 2)
+  const int xrows_valid = C::S2 ? 4 * spr : (R + 2 * HALO) * PW;
   auto piece_offsets = [&](const PTile& t) __attribute__((always_inline)) {
 #pragma unroll
     for (int m = 0; m < C::PIT; ++m) {
       const int j = 16 * (wave + C::NW * m) + lrow;
-      const int rj = j / PW, cj = j - rj * PW;
-      const int iy = t.y0 - HALO + rj, ix = cj - 1;
-      const bool ok = j < xrows_valid && cj >= 1 && (unsigned)iy < (unsigned)H;
+      int iy, ix;
+      bool ok = j < xrows_valid;
+      if (C::S2) {
+        const int sp = j / spr, jj = j - sp * spr;
+        const int rr = jj / PW, cc = jj - rr * PW;
+        iy = 2 * (t.y0 + rr - 1) + (sp >> 1);
+        ix = 2 * (cc - 1) + (sp & 1);
+        ok = ok && (unsigned)ix < (unsigned)W && (unsigned)iy < (unsigned)H;
+      } else {
+        const int rj = j / PW, cj = j - rj * PW;
+        iy = t.y0 - HALO + rj; ix = cj - 1;
+        ok = ok && cj >= 1 && (unsigned)iy < (unsigned)H;
+      }
       const int lc = lchunk ^ ((j >> 2) & 3);
       st.pvoff[m] = ok ? ((iy * W + ix) * a.ldx + lc * 8) * 2 : (int)0x80000000;
     }
@@ -300,7 +317,8 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void planes_kernel(const Pla
   auto tap_offsets = [&](int dshift) __attribute__((always_inline)) {
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-      const int row = idx0 + (t / 3) * PW + (t % 3) + dshift;
+      const int kh = t / 3, kw = t % 3;
+      const int row = C::S2 ? ((kh != 1) * 2 + (kw != 1)) * spr + idx0 + (kh != 0) * PW + (kw != 0) : idx0 + kh * PW + kw + dshift;
       st.tb[t] = row * ROWB + ((h ^ ((row >> 2) & 3)) << 4);
     }
   };
@@ -433,9 +451,9 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void planes_kernel(const Pla
       };
       const int c0 = cur.ch + wc * 32 + 16 * h;
       const Store2 store2{
-          __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)cur.b * a.y_bstride), 0, (int)((long)H * W * a.ldy * 2), 0x00020000),
-          __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res + (long)cur.b * a.r_bstride : a.x), 0, (int)((long)H * W * (RES ? a.ldr : a.ldx) * 2), 0x00020000),
-          wp, l31, PW, W, R, H, cur.y0, a.ldy, a.ldr, c0, c0 + 16 <= a.Cout, 1.0f / (float)PW};
+          __builtin_amdgcn_make_buffer_rsrc((void*)(a.y + (long)cur.b * a.y_bstride), 0, (int)((long)Ho * Wo * a.ldy * 2), 0x00020000),
+          __builtin_amdgcn_make_buffer_rsrc((void*)(RES ? a.res + (long)cur.b * a.r_bstride : a.x), 0, (int)((long)Ho * Wo * (RES ? a.ldr : a.ldx) * 2), 0x00020000),
+          wp, l31, PW, Wo, R, Ho, cur.y0, a.ldy, a.ldr, c0, c0 + 16 <= a.Cout, 1.0f / (float)PW};
       const float16v bv2 = load_bias(a.bb, cur.ch);
       auto setup2 = [&](int p) __attribute__((always_inline)) {
         bool pieces = false;
@@ -504,26 +522,29 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void planes_kernel(const Pla
 template <class C>
 bool planes_geometry(const PlanesArgs& a, PlanesGeom* g) {
   constexpr int HALO = C::PAIR ? 2 : 1;
-  const int PW = a.W + 1;
+  if (C::S2 && ((a.H | a.W) & 1)) return false;
+  const int Ho = C::S2 ? a.H / 2 : a.H, Wo = C::S2 ? a.W / 2 : a.W;
+  const int PW = Wo + 1;
+  auto rows_of = [&](int R) { return C::S2 ? 4 * (R + 1) * PW : (R + 2 * HALO) * PW + 1; };   // storage indices of an input plane
   int R = 32 * C::NB2 / PW;                                      // R * PW <= 32 * NB2
   if (C::PAIR) R = std::min(R, (32 * C::NB1 - 1) / PW - 2);      // (R + 2) * PW + 1 <= 32 * NB1: the pad after the last row is computed (as zero)
-  R = std::min(R, a.H);
+  R = std::min(R, Ho);
   const int NP = a.Cin / 32;
   for (; R >= 1; --R) {
-    const int npieces = ((R + 2 * HALO) * PW + 1 + 15) / 16;
+    const int npieces = (rows_of(R) + 15) / 16;
     if (npieces > C::NW * C::PIT) continue;
     const int inter = C::PAIR ? C::WC * 32 * C::NB1 * ROWB : 0;
     if (inter + 2 * npieces * 1024 + 1024 > LDS_MAX) continue;
     break;
   }
   if (R < 1) return false;
-  const int nslab = (a.H + R - 1) / R;
-  R = (a.H + nslab - 1) / nslab;                                 // equal slabs
+  const int nslab = (Ho + R - 1) / R;
+  R = (Ho + nslab - 1) / nslab;                                 // equal slabs
   // the kernel always runs its NPB2 (and NPB1) pixel blocks: refuse geometries that leave them mostly empty
   if ((long)R * PW * 10 < (long)32 * C::NB2 * 6) return false;
   g->R = R; g->nslab = nslab; g->PW = PW;
   g->irows = 32 * C::NB1;
-  g->npieces = ((R + 2 * HALO) * PW + 1 + 15) / 16;
+  g->npieces = (rows_of(R) + 15) / 16;
   g->xrows = 16 * g->npieces;
   g->NP = NP; g->NPo = C::WC;
   g->tiles_ch = C::PAIR ? 1 : (a.Cout + 32 * C::WC - 1) / (32 * C::WC);
@@ -564,13 +585,15 @@ using P128 = PCfg<4, 9, 7, true, 1>;    // 128 hidden channels: 40 x 40 maps in 
 using P64 = PCfg<2, 8, 6, true, 2>;     // 64 hidden channels: 80 x 80 maps in slabs of 4 rows (16 / 12 pixel blocks over two pixel groups).  (Measured on eight
                                         // waves, <2, 4, 3, true, 1, 8>: 256 registers per wave do not hold the pipe -- 70 spills, 91 us per pair.)
 using S64 = PCfg<2, 0, 4, false, 1>;    // single conv, 64-channel tiles: 20 x 20 maps in slabs of 10 rows
+using S64S2 = PCfg<2, 0, 4, false, 3, 4, true>;   // ... stride 2: 80 -> 40 in slabs of 5 output rows, 40 -> 20 in slabs of 10
+using S128S2 = PCfg<4, 0, 7, false, 3, 4, true>;  // stride 2, 128-channel tiles: half the input re-reads and LDS-DMA issues per MFMA of the 64-channel form
 
 }  // namespace
 
 // Shape-only eligibility (graph construction): an instance exists for C hidden channels and its row slabs fit LDS.
 bool bneck_pair_shape_ok(int C, int H, int W) {
   PlanesArgs a{};
-  a.H = H; a.W = W; a.B = 1; a.Cin = a.Cout = C;
+  a.H = H; a.W = W; a.B = 1; a.Cin = a.Cout = C; a.stride = 1;
   PlanesGeom g;
   if (C == 128) return planes_geometry<P128>(a, &g);
   // 64 hidden channels: measured 58 us per pair on the 80 x 80 level at batch 32 against 56 for the two conv3x3_halo launches -- a
@@ -599,16 +622,38 @@ int launch_bneck_pair(const PlanesArgs& a, hipStream_t s) {
 }
 
 // One 3x3 conv (+ SiLU, + residual) over row slabs, 64-channel output tiles.
+namespace {
+// Stride 2: which channel tile?  Every tile streams the whole input slab, so the 128-channel form halves the L2 -> LDS traffic and
+// the LDS-DMA issues (~120 cycles each beside the MFMAs: 16 per wave and phase on an 80 x 80 input) per MFMA; it needs >= one tile
+// per CU to pay.  Cost model in cycles per block: tiles x phases x (MFMA slots x 33 + pieces x 120 + 700).
+template <class C>
+long planes_cost(const PlanesArgs& a, PlanesGeom* g) {
+  if (!planes_geometry<C>(a, g)) return -1;
+  if (C::WC == 4 && a.Cout % 128) return -1;
+  int dev = 0, cus = 256;
+  if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+  const long rounds = (g->ntiles + cus - 1) / cus;
+  return rounds * g->NP * ((long)C::NPB2 * 18 * 33 + (long)((g->npieces + C::NW - 1) / C::NW) * 120 + 700);
+}
+}  // namespace
+
 bool conv3x3_planes_ok(const PlanesArgs& a) {
-  if (!planes_common_ok(a)) return false;
+  if (!planes_common_ok(a) || (a.stride != 1 && a.stride != 2)) return false;
   if ((a.Cin / 32) % 2 || a.Cout % 8 || a.cblocks_b * 32 < (a.Cout + 63) / 64 * 64) return false;   // (the input ring alternates slots across tiles: even plane count)
+  if (a.stride == 2 && a.res) return false;
   PlanesGeom g;
-  return planes_geometry<S64>(a, &g);
+  return a.stride == 2 ? (planes_geometry<S64S2>(a, &g) || (a.Cout % 128 == 0 && planes_geometry<S128S2>(a, &g))) : planes_geometry<S64>(a, &g);
 }
 
 int launch_conv3x3_planes(const PlanesArgs& a, hipStream_t s) {
   if (!conv3x3_planes_ok(a)) return -1;
   PlanesGeom g;
+  if (a.stride == 2) {
+    PlanesGeom g2;
+    const long c64 = planes_cost<S64S2>(a, &g), c128 = planes_cost<S128S2>(a, &g2);
+    if (c128 >= 0 && (c64 < 0 || c128 < c64)) return planes_launch<S128S2>(a, g2, s);
+    return c64 >= 0 ? planes_launch<S64S2>(a, g, s) : -1;
+  }
   return planes_geometry<S64>(a, &g) ? planes_launch<S64>(a, g, s) : -1;
 }
 

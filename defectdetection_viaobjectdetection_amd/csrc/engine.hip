@@ -899,19 +899,21 @@ void annotate_ops(m355_engine* e) {
         }
         // row-slab kernel in single-conv mode (conv3x3_planes.hip) for what the slab kernel took (the 20 x 20 level): one block per CU
         // owns a slab x 64 channels with its weights streamed to registers -- 21 us against 34 on 256 -> 256 at batch 32
-        if (op.kind == OP_CONV && op.tile == TILE_SLAB && op.out_ext == 0 && p.l3 < 0 && !p.diag && !getenv("M355_NO_PLANES")) {
+        // ... and for the stride-2 3x3 convs that were on the im2col kernel (model.5 / 7 / 16 / 19 of the s scale: 177 us at batch 32)
+        const bool planes_s2 = p.k == 3 && p.stride == 2 && op.res.t < 0 && op.in2.t < 0 && !op.s2c32 && !op.s2c64 && !getenv("M355_NO_PLANES_S2");
+        if (op.kind == OP_CONV && (op.tile == TILE_SLAB || planes_s2) && op.out_ext == 0 && p.l3 < 0 && !p.diag && !getenv("M355_NO_PLANES")) {
           const Tensor& to2 = e->tensors[op.out.t];
           PlanesArgs pa{};
           pa.x = ti.p; pa.y = to2.p; pa.wfb = (const half_t*)1; pa.bb = (const float*)1;   // (shape check only)
           pa.x_bstride = (long)ti.H * ti.W * ti.C; pa.ldx = ti.C; pa.H = ti.H; pa.W = ti.W; pa.B = e->desc.max_batch; pa.Cin = p.cin; pa.Cout = p.cout;
-          pa.cblocks_b = (p.cout + 63) / 64 * 2; pa.ldy = to2.C; pa.act = p.act;
+          pa.cblocks_b = (p.cout + 63) / 64 * 2; pa.ldy = to2.C; pa.act = p.act; pa.stride = p.stride;
           if (conv3x3_planes_ok(pa)) {
             op.tile = TILE_PLANES;
             e->phys[op.conv].planes = 1;
           }
         }
         if (op.tile == TILE_PLANES)
-          snprintf(op.kernel, sizeof(op.kernel), "conv3x3_planes<64ch,rows>");
+          snprintf(op.kernel, sizeof(op.kernel), p.stride == 2 ? "conv3x3_planes<64ch,rows,s2>" : "conv3x3_planes<64ch,rows>");
         else if (op.tile == TILE_W1)
           snprintf(op.kernel, sizeof(op.kernel), "conv1x1_wreg<K%d,%dch>", p.cin, cout_v % 256 == 0 ? 256 : 128);
         else if (op.tile == TILE_C32)
@@ -1558,10 +1560,10 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         if (op.tile == TILE_PLANES) {
           PlanesArgs pa{};
           pa.x = a.x; pa.x_bstride = a.x_bstride; pa.ldx = a.ldx; pa.H = a.Hi; pa.W = a.Wi; pa.B = Bq; pa.Cin = p.cin; pa.Cout = p.cout;
-          pa.wfb = p.wf; pa.cblocks_b = (p.cout + 63) / 64 * 2; pa.bb = p.bias; pa.act = p.act;
+          pa.wfb = p.wf; pa.cblocks_b = (p.cout + 63) / 64 * 2; pa.bb = p.bias; pa.act = p.act; pa.stride = p.stride;
           pa.y = (half_t*)a.y; pa.y_bstride = a.y_bstride; pa.ldy = a.ldy;
           pa.res = a.res; pa.r_bstride = a.r_bstride; pa.ldr = a.ldr;
-          rc = (p.wf && conv3x3_planes_ok(pa)) ? launch_conv3x3_planes(pa, s) : launch_conv3x3_slab(a, s);
+          rc = (p.wf && conv3x3_planes_ok(pa)) ? launch_conv3x3_planes(pa, s) : (p.stride == 1 ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, TILE_AUTO, s));
           break;
         }
         rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
@@ -1596,7 +1598,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
         a.x_bstride = (long)ti.H * ti.W * ti.C; a.ldx = ti.C; a.H = ti.H; a.W = ti.W; a.B = Bq; a.Cin = pa.cin; a.Cout = pb.cout;
         a.x = ti.p + op.in.off + b0 * a.x_bstride;
         a.wfa = pa.wf; a.wfb = pb.wf; a.cblocks_a = (pa.cout + 63) / 64 * 2; a.cblocks_b = (pb.cout + 63) / 64 * 2;
-        a.ba = pa.bias; a.bb = pb.bias; a.act = 1;
+        a.ba = pa.bias; a.bb = pb.bias; a.act = 1; a.stride = 1;
         a.y_bstride = (long)to.H * to.W * to.C; a.ldy = to.C;
         a.y = to.p + op.out.off + b0 * a.y_bstride;
         if (op.shortcut) { a.res = a.x; a.r_bstride = a.x_bstride; a.ldr = a.ldx; }
@@ -1800,8 +1802,8 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
     int bch = 0, bpx = 0;
     if (!conv_forced_tile_extent(force_tile & 0xff, cout_v, &bch, &bpx))
       return set_err(M355_ERR_INVALID, "unknown forced tile id " + std::to_string(force_tile & 0xff));
-    if ((force_tile & 0xff) == TILE_PLANES && (transposed || k != 3 || stride != 1 || cin % 32 || out_f32))
-      return set_err(M355_ERR_INVALID, "forced tile TILE_PLANES takes 3x3 / stride 1 convs with cin % 32 == 0 and fp16 output only");
+    if ((force_tile & 0xff) == TILE_PLANES && (transposed || k != 3 || (stride != 1 && stride != 2) || cin % 32 || out_f32))
+      return set_err(M355_ERR_INVALID, "forced tile TILE_PLANES takes 3x3 convs of stride 1 or 2 with cin % 32 == 0 and fp16 output only");
     if ((cout_v + bch - 1) / bch * bch > cout_pad)
       return set_err(M355_ERR_INVALID, "forced tile reads " + std::to_string((cout_v + bch - 1) / bch * bch) +
                                            " weight rows, the packed buffer has " + std::to_string(cout_pad));
@@ -1870,7 +1872,7 @@ static int conv_op_common(const void* d_x, int B, int H, int W, int cin, const f
     HIP_TRYG(hipMalloc((void**)&dpf, fp.size() * sizeof(half_t)));
     HIP_TRYG(hipMemcpy(dpf, fp.data(), fp.size() * sizeof(half_t), hipMemcpyHostToDevice));
     PlanesArgs pa{};
-    pa.x = a.x; pa.x_bstride = a.x_bstride; pa.ldx = a.ldx; pa.H = H; pa.W = W; pa.B = B; pa.Cin = cin; pa.Cout = cout;
+    pa.x = a.x; pa.x_bstride = a.x_bstride; pa.ldx = a.ldx; pa.H = H; pa.W = W; pa.B = B; pa.Cin = cin; pa.Cout = cout; pa.stride = stride;
     pa.wfb = dpf; pa.cblocks_b = cbl; pa.bb = db; pa.y = (half_t*)d_y; pa.y_bstride = a.y_bstride; pa.ldy = a.ldy;
     pa.res = a.res; pa.r_bstride = a.r_bstride; pa.ldr = a.ldr; pa.act = act; pa.stamps = d_st;
     rc = conv3x3_planes_ok(pa) ? launch_conv3x3_planes(pa, s) : -1;
@@ -1987,7 +1989,7 @@ int m355_bneck_pair_fwd(const void* d_x, int B, int H, int W, int C, int ldx, co
   a.x = (const half_t*)d_x; a.x_bstride = (long)H * W * ldx; a.ldx = ldx; a.H = H; a.W = W; a.B = B; a.Cin = C; a.Cout = C;
   a.wfa = dw; a.wfb = dw + fa.size(); a.cblocks_a = a.cblocks_b = cbl;
   a.ba = db; a.bb = db + rows;
-  a.y = (half_t*)d_y; a.y_bstride = (long)H * W * ldy; a.ldy = ldy; a.act = 1;
+  a.y = (half_t*)d_y; a.y_bstride = (long)H * W * ldy; a.ldy = ldy; a.act = 1; a.stride = 1;
   if (shortcut) { a.res = a.x; a.r_bstride = a.x_bstride; a.ldr = ldx; }
   unsigned long long* d_st = nullptr;
   const char* st_path = getenv("M355_STAMPS");

@@ -95,6 +95,39 @@ def test_bneck_pair_refuses_what_it_cannot_tile(cuda_device):
     assert rc != 0            # a 700-pixel row does not fit the pixel blocks of one slab
 
 
+S2_CASES = [
+    # B, H, W (input), cin, cout
+    (2, 80, 80, 128, 256),       # model.5 of the s scale: slabs of 5 output rows
+    (3, 40, 40, 256, 512),       # model.7: slabs of 10 rows, eight channel tiles
+    (2, 80, 80, 128, 128),       # model.16
+    (1, 28, 44, 64, 192),        # ragged: 14 x 22 output, slabs of 7 rows
+    (36, 40, 40, 256, 256),      # model.19 at a batch where blocks walk two tiles
+]
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout", S2_CASES)
+def test_conv3x3_planes_stride2_against_torch(cuda_device, B, H, W, cin, cout):
+    """Stride 2 on the row-slab kernel: the input plane de-interleaved into four parity sub-planes by the DMA's source addresses."""
+    from defectdetection_viaobjectdetection_amd import _capi
+    g = torch.Generator().manual_seed(B * 100 + H + cin + cout)
+    r16 = lambda t: t.half().float()
+    x = (torch.randn((B, cin, H, W), generator=g) * 0.8).half()
+    w = r16(torch.randn((cout, cin, 3, 3), generator=g) * (2.0 / (9 * cin)) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.3
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda_device)
+    yd = torch.full((B, H // 2, W // 2, cout), float("nan"), dtype=torch.float16, device=cuda_device)
+    wn, bn = w.numpy().astype(np.float32).copy(), b.numpy().astype(np.float32).copy()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _capi.check(_capi.lib.m355_conv2d_fwd(C.c_void_p(xd.data_ptr()), B, H, W, cin, _h(wn), _h(bn), cout, 3, 2, 1, None,
+                                          C.c_void_p(yd.data_ptr()), 0, 33, st))
+    got = yd.float().cpu().permute(0, 3, 1, 2)
+    want = F.silu(F.conv2d(x.float(), w, b, stride=2, padding=1))
+    assert torch.isfinite(got).all()
+    rel = float((got - want).norm() / want.norm())
+    print(f"s2 B={B} {H}x{W} {cin}->{cout}: rel-L2 {rel:.2e}")
+    assert rel <= 1e-3
+
+
 SINGLE_CASES = [
     # B, H, W, cin, cout, residual
     (3, 20, 20, 256, 256, False),     # the stride-32 level at 640 x 640: two slabs of 10 rows, four 64-channel tiles

@@ -6,10 +6,10 @@ os.environ["M355_BNECK_REPS"] = "50"
 from defectdetection_viaobjectdetection_amd import _capi
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 h = lambda a: a.ctypes.data_as(C.c_void_p)
-for (H, W, ci, co) in ((20, 20, 256, 256), (20, 20, 256, 64), (20, 20, 128, 128), (40, 40, 128, 128), (40, 40, 256, 224)):
+for (H, W, ci, co, st) in ((20, 20, 256, 256, 1), (80, 80, 128, 256, 2), (40, 40, 256, 512, 2), (80, 80, 128, 128, 2), (40, 40, 256, 256, 2)):
     x = torch.randn(B, H, W, ci, device="cuda").half()
-    y = torch.empty(B, H, W, co, device="cuda", dtype=torch.float16)
+    y = torch.empty(B, H // st, W // st, co, device="cuda", dtype=torch.float16)
     w = (np.random.default_rng(0).standard_normal((co, ci, 3, 3)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
     b = np.zeros(co, np.float32)
-    rc = _capi.lib.m355_conv2d_fwd(C.c_void_p(x.data_ptr()), B, H, W, ci, h(w), h(b), co, 3, 1, 1, None, C.c_void_p(y.data_ptr()), 0, 33, None)
-    print((H, W, ci, co), "rc", rc, f"{2 * 9 * ci * co * B * H * W / 1e9:.1f} GFLOP")
+    rc = _capi.lib.m355_conv2d_fwd(C.c_void_p(x.data_ptr()), B, H, W, ci, h(w), h(b), co, 3, st, 1, None, C.c_void_p(y.data_ptr()), 0, 33, None)
+    print((H, W, ci, co, st), "rc", rc, f"{2 * 9 * ci * co * B * H * W / st / st / 1e9:.1f} GFLOP")
