@@ -308,8 +308,9 @@ def test_conv_plus_cv1_fusion_is_bit_identical(cuda_device):
     from defectdetection_viaobjectdetection_amd.engine import SegEngine
     from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
     # the 32 -> 64 pair has its own patch kernel by default (next test) and the separate 128 -> 128 cv1 would run on the
-    # weights-in-registers 1x1 kernel (another summation order): this test is about the im2col kernel's epilogue fusion
-    knobs = {"M355_NO_S2C32": "1", "M355_NO_W1": "1", "M355_NO_S2C64": "1"}
+    # weights-in-registers 1x1 kernel (another summation order), a separate stride-2 conv on the row-slab kernel (round 4) likewise:
+    # this test is about the im2col kernel's epilogue fusion
+    knobs = {"M355_NO_S2C32": "1", "M355_NO_W1": "1", "M355_NO_S2C64": "1", "M355_NO_PLANES_S2": "1"}
     os.environ.update(knobs)
     try:
         _cv1_fusion_cases(cuda_device)
