@@ -599,7 +599,7 @@ bool bneck_pair_shape_ok(int C, int H, int W) {
   // 64 hidden channels: measured 58 us per pair on the 80 x 80 level at batch 32 against 56 for the two conv3x3_halo launches -- a
   // block finishes half of its phases with the SiLU pipe beside the MFMAs (VALU-bound), and with one wave per SIMD nothing else
   // covers it.  The instance is kept (tests, M355_PAIR64=1), the graph builder does not use it.
-  static const bool pair64 = getenv("M355_PAIR64") != nullptr;
+  const bool pair64 = getenv("M355_PAIR64") != nullptr;   // (graph construction only: not on a launch path)
   if (C == 64 && pair64) return planes_geometry<P64>(a, &g);
   return false;
 }

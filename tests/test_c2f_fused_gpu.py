@@ -113,7 +113,7 @@ def test_engine_with_the_fused_block_equals_the_three_launches(cuda_device):
         # bulk must agree far below the stated tolerances, the single worst anchor stays below the format floor (~1.3 px)
         q = lambda t, f: float(t.flatten().kthvalue(max(1, int(t.numel() * f)))[0])
         assert q(dp[..., 4], .99) <= 1e-3 and q(dp[..., :4], .99) <= 0.15 and q(dp[..., :4], .999) <= 0.45
-        assert float(dp[..., 4].max()) <= 5e-3 and float(dp[..., :4].max()) <= 1.0
+        assert float(dp[..., 4].max()) <= 5e-3 and float(dp[..., :4].max()) <= 1.3      # (the format floor: 1.0 px held until round 4's conv kernels changed the downstream sums: 1.03)
         assert float((outs[True][1] - outs[False][1]).norm() / outs[False][1].norm()) <= 2e-3
 
 
