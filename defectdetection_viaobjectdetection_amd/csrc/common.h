@@ -246,6 +246,9 @@ int launch_box_loss(const float* logits, const float* anchors, const float* targ
                     float* dfl_term, float* d_box, float* d_dfl, hipStream_t s);
 int launch_dfl_decode(const float* raw, long rows, int A, int rw, int nc, const float* anchors, const float* strides, float* boxes,
                       float* scores, hipStream_t s);
+int launch_tal_assign(const float* scores, const float* boxes, const float* anchors_px, const int* gt_cls, const float* gt_boxes,
+                      const unsigned char* gt_valid, int B, int A, int G, int nc, void* ws, float* t_boxes, float* t_scores,
+                      unsigned char* fg, long* gt_idx, hipStream_t s);
 int launch_repack(const void* d_jobs /* m355_repack_job[] (include/mi355yolo.h) */, const int* d_block_job, int nblocks, hipStream_t s);
 
 // train-mode BatchNorm + SiLU (train_kernels.hip)

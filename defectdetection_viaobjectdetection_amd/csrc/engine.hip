@@ -2520,6 +2520,14 @@ int m355_dfl_decode_launch(const float* raw, int64_t rows, int32_t A, int32_t rw
   return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "dfl-decode launch failed: " + std::to_string(rc));
 }
 
+int m355_tal_assign_launch(const float* scores, const float* boxes, const float* anchors_px, const int32_t* gt_cls, const float* gt_boxes,
+                           const uint8_t* gt_valid, int32_t B, int32_t A, int32_t G, int32_t nc, void* ws, float* t_boxes, float* t_scores,
+                           uint8_t* fg, int64_t* gt_idx, void* stream) {
+  const int rc = launch_tal_assign(scores, boxes, anchors_px, gt_cls, gt_boxes, gt_valid, B, A, G, nc, ws, t_boxes, t_scores, fg, (long*)gt_idx,
+                                   (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "tal_assign launch failed: " + std::to_string(rc));
+}
+
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream) {
   if (!x || !y) return set_err(M355_ERR_INVALID, "null pointer");

@@ -340,6 +340,177 @@ __global__ __launch_bounds__(256) void dfl_decode_kernel(const float* raw, long 
     scores[(r0 + rr) * nc + c] = sigmoid_exact(tile[rr * pitch + 4 * REGM + c]);
   }
 }
+// ---------------------------------------------------------------------------------------------------------------------------
+// Task-aligned assignment (upstream TaskAlignedAssigner, reached from
+// /root/reference/BscanBased/yolo_seg_train.py:12): loss.assign_targets as two kernels instead of ~40 torch launches on
+// (B, G, A) tensors (round-3 verdict: "task-aligned assignment + class BCE as one or two kernels").
+//   tal_topk_kernel     one block per (image, ground truth): candidate test (anchor centre strictly inside the box), CIoU with the
+//                       predicted box (the expression loss.ciou evaluates, fp32), metric = score^0.5 * CIoU^6, the ten largest
+//                       metrics (ties: lower anchor index) -> per (b, g) ten (anchor, metric, overlap) records; a picked anchor that
+//                       is no candidate is dropped (top & cand)
+//   tal_resolve_kernel  one block per image: an anchor claimed by several ground truths goes to the one with the highest CIoU over
+//                       ALL ground truths (first maximum), the per-truth maxima of metric and overlap over the final positives give
+//                       norm = metric * max_overlap / (max_metric + eps); writes target boxes / scores / foreground / index for the
+//                       positives only (the outputs are zero-filled by the caller)
+// ---------------------------------------------------------------------------------------------------------------------------
+constexpr int TAL_K = 10;
+
+__device__ __forceinline__ float tal_ciou(const float* g, const float* b) {   // loss.ciou(gt, pred), complete
+  const float eps = 1e-7f;
+  const float aw = g[2] - g[0], ah = g[3] - g[1] + eps;
+  const float bw = b[2] - b[0], bh = b[3] - b[1] + eps;
+  const float iw = fmaxf(fminf(g[2], b[2]) - fmaxf(g[0], b[0]), 0.f);
+  const float ih = fmaxf(fminf(g[3], b[3]) - fmaxf(g[1], b[1]), 0.f);
+  const float inter = iw * ih;
+  const float iou = inter / (aw * ah + bw * bh - inter + eps);
+  const float cw = fmaxf(g[2], b[2]) - fminf(g[0], b[0]);
+  const float ch = fmaxf(g[3], b[3]) - fminf(g[1], b[1]);
+  const float diag2 = cw * cw + ch * ch + eps;
+  const float dx = b[0] + b[2] - g[0] - g[2], dy = b[1] + b[3] - g[1] - g[3];
+  const float centre2 = (dx * dx + dy * dy) * 0.25f;
+  const float da = atanf(bw / bh) - atanf(aw / ah);
+  const float v = 0.40528473456935109f * da * da;                             // 4 / pi^2
+  const float alpha = v / (v - iou + (1.0f + eps));
+  return iou - (centre2 / diag2 + v * alpha);
+}
+__device__ __forceinline__ bool tal_cand(const float* g, float ax, float ay) {
+  const float d = fminf(fminf(ax - g[0], ay - g[1]), fminf(g[2] - ax, g[3] - ay));
+  return d > 1e-9f;
+}
+__device__ __forceinline__ float tal_metric(float score, float ov) {         // score^0.5 * ov^6 (ov >= 0)
+  const float o2 = ov * ov;
+  return sqrtf(score) * (o2 * o2 * o2);
+}
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void tal_topk_kernel(const float* scores, const float* boxes, const float* anchors_px, const int* gt_cls,
+                                                      const float* gt_boxes, const unsigned char* gt_valid, int A, int G, int nc,
+                                                      int* top_idx, float* top_metric, float* top_overlap) {
+  extern __shared__ float sm[];          // A metrics + A overlaps
+  float* met = sm;
+  float* ovl = sm + A;
+  __shared__ float rv[256];
+  __shared__ int ri[256];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const long bg = (long)b * G + g;
+  const float gb[4] = {gt_boxes[bg * 4], gt_boxes[bg * 4 + 1], gt_boxes[bg * 4 + 2], gt_boxes[bg * 4 + 3]};
+  const bool valid = gt_valid[bg] != 0;
+  int c = gt_cls[bg];
+  c = c < 0 ? 0 : (c > nc - 1 ? nc - 1 : c);
+  for (int a = tid; a < A; a += 256) {
+    const bool cand = valid && tal_cand(gb, anchors_px[2 * a], anchors_px[2 * a + 1]);
+    float ov = 0.f, m = 0.f;
+    if (cand) {
+      const float* pb = boxes + ((long)b * A + a) * 4;
+      const float bx[4] = {pb[0], pb[1], pb[2], pb[3]};
+      ov = fmaxf(tal_ciou(gb, bx), 0.f);
+      m = tal_metric(scores[((long)b * A + a) * nc + c], ov);
+    }
+    ovl[a] = ov;
+    met[a] = cand ? m : -1.0f;           // non-candidates can be picked by upstream's topk only among zero ties, and are dropped again
+  }
+  __syncthreads();
+  for (int k = 0; k < TAL_K; ++k) {
+    float best = -2.0f;
+    int bi = 0x7fffffff;
+    for (int a = tid; a < A; a += 256) {
+      const float m = met[a];
+      if (m > best) { best = m; bi = a; }   // ascending a: the first maximum of this thread's anchors
+    }
+    rv[tid] = best; ri[tid] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        const float o = rv[tid + s];
+        const int oi = ri[tid + s];
+        if (o > rv[tid] || (o == rv[tid] && oi < ri[tid])) { rv[tid] = o; ri[tid] = oi; }
+      }
+      __syncthreads();
+    }
+    if (tid == 0) {
+      const int a = ri[0];
+      const bool pos = rv[0] >= 0.f && a < A;          // a candidate (metric may be 0: upstream keeps it when it is among the top ten)
+      top_idx[bg * TAL_K + k] = pos ? a : -1;
+      top_metric[bg * TAL_K + k] = pos ? rv[0] : 0.f;
+      top_overlap[bg * TAL_K + k] = pos ? ovl[a] : 0.f;
+      if (a < A) met[a] = -3.0f;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void tal_resolve_kernel(const float* scores, const float* boxes, const float* anchors_px, const int* gt_cls,
+                                                         const float* gt_boxes, const unsigned char* gt_valid, int A, int G, int nc,
+                                                         const int* top_idx, const float* top_metric, const float* top_overlap,
+                                                         float* t_boxes, float* t_scores, unsigned char* fg, long* gt_idx) {
+  extern __shared__ int smi[];            // n anchors | n final g | n metric | n overlap | G max metric | G max overlap
+  const int b = blockIdx.x, tid = threadIdx.x, n = G * TAL_K;
+  int* e_a = smi;
+  int* e_g = smi + n;
+  float* e_m = (float*)(smi + 2 * n);
+  float* e_o = (float*)(smi + 3 * n);
+  float* mx_m = (float*)(smi + 4 * n);
+  float* mx_o = mx_m + G;
+  for (int e = tid; e < n; e += 256) e_a[e] = top_idx[(long)b * n + e];
+  for (int g = tid; g < G; g += 256) { mx_m[g] = 0.f; mx_o[g] = 0.f; }
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {
+    const int a = e_a[e];
+    int fgq = -1;
+    float m = 0.f, o = 0.f;
+    if (a >= 0) {
+      int claims = 0, first = e;
+      for (int f = 0; f < n; ++f)
+        if (e_a[f] == a) { ++claims; first = f < first ? f : first; }
+      if (claims == 1) {
+        fgq = e / TAL_K; m = top_metric[(long)b * n + e]; o = top_overlap[(long)b * n + e];
+      } else if (first == e) {            // one record per multiply-claimed anchor: the ground truth with the highest overlap of ALL
+        const float ax = anchors_px[2 * a], ay = anchors_px[2 * a + 1];
+        const float* pb = boxes + ((long)b * A + a) * 4;
+        const float bx[4] = {pb[0], pb[1], pb[2], pb[3]};
+        float best = -1.f;
+        for (int g = 0; g < G; ++g) {
+          const float* gp = gt_boxes + ((long)b * G + g) * 4;
+          const float gb[4] = {gp[0], gp[1], gp[2], gp[3]};
+          const bool cand = gt_valid[(long)b * G + g] != 0 && tal_cand(gb, ax, ay);
+          const float ov = cand ? fmaxf(tal_ciou(gb, bx), 0.f) : 0.f;
+          if (ov > best) { best = ov; fgq = g; }
+        }
+        int c = gt_cls[(long)b * G + fgq];
+        c = c < 0 ? 0 : (c > nc - 1 ? nc - 1 : c);
+        o = best;
+        const float* gp = gt_boxes + ((long)b * G + fgq) * 4;
+        const float gb[4] = {gp[0], gp[1], gp[2], gp[3]};
+        const bool cand = gt_valid[(long)b * G + fgq] != 0 && tal_cand(gb, ax, ay);
+        m = cand ? tal_metric(scores[((long)b * A + a) * nc + c], o) : 0.f;
+      }
+    }
+    e_g[e] = fgq; e_m[e] = m; e_o[e] = o;
+  }
+  __syncthreads();
+  for (int g = tid; g < G; g += 256) {   // maxima over the truth's final positives (fixed order)
+    float mm = 0.f, mo = 0.f;
+    for (int e = 0; e < n; ++e)
+      if (e_g[e] == g) { mm = fmaxf(mm, e_m[e]); mo = fmaxf(mo, e_o[e]); }
+    mx_m[g] = mm; mx_o[g] = mo;
+  }
+  __syncthreads();
+  for (int e = tid; e < n; e += 256) {
+    const int g = e_g[e];
+    if (g < 0) continue;
+    const int a = e_a[e];
+    const long ba = (long)b * A + a;
+    const float norm = e_m[e] * mx_o[g] / (mx_m[g] + 1e-9f);
+    int c = gt_cls[(long)b * G + g];
+    c = c < 0 ? 0 : (c > nc - 1 ? nc - 1 : c);
+    const float* gp = gt_boxes + ((long)b * G + g) * 4;
+    t_boxes[ba * 4] = gp[0]; t_boxes[ba * 4 + 1] = gp[1]; t_boxes[ba * 4 + 2] = gp[2]; t_boxes[ba * 4 + 3] = gp[3];
+    t_scores[ba * nc + c] = norm;
+    fg[ba] = 1;
+    gt_idx[ba] = g;
+  }
+}
+
 }  // namespace
 
 int launch_box_loss(const float* logits, const float* anchors, const float* targets, const float* weights, long n, float* box_term,
@@ -384,6 +555,31 @@ int launch_mask_loss(const float* coef, const void* protos, int protos_f16, cons
     else M355_PROTO_LAUNCH(false, false);
 #undef M355_PROTO_LAUNCH
   }
+  return (int)hipGetLastError();
+}
+
+// Task-aligned assignment on the device.  scores (B,A,nc), boxes (B,A,4) xyxy px, anchors_px (A,2), gt_cls (B,G) int32, gt_boxes
+// (B,G,4), gt_valid (B,G) bytes; ws: (B * G * 10) ints + 2 x (B * G * 10) floats; the four outputs must be zero on entry.
+int launch_tal_assign(const float* scores, const float* boxes, const float* anchors_px, const int* gt_cls, const float* gt_boxes,
+                      const unsigned char* gt_valid, int B, int A, int G, int nc, void* ws, float* t_boxes, float* t_scores,
+                      unsigned char* fg, long* gt_idx, hipStream_t s) {
+  if (B < 1 || A < 1 || G < 1 || nc < 1 || !ws) return -1;
+  const long n = (long)B * G * TAL_K;
+  int* top_idx = (int*)ws;
+  float* top_metric = (float*)ws + n;
+  float* top_overlap = (float*)ws + 2 * n;
+  const size_t lds1 = (size_t)2 * A * sizeof(float), lds2 = (size_t)(4 * G * TAL_K + 2 * G) * sizeof(int);
+  if (lds1 > 150 * 1024 || lds2 > 150 * 1024) return -1;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)tal_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return -2;
+    if (hipFuncSetAttribute((const void*)tal_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return -2;
+    attr = true;
+  }
+  hipLaunchKernelGGL(tal_topk_kernel, dim3(G, B), dim3(256), lds1, s, scores, boxes, anchors_px, gt_cls, gt_boxes, gt_valid, A, G, nc, top_idx,
+                     top_metric, top_overlap);
+  hipLaunchKernelGGL(tal_resolve_kernel, dim3(B), dim3(256), lds2, s, scores, boxes, anchors_px, gt_cls, gt_boxes, gt_valid, A, G, nc, top_idx,
+                     top_metric, top_overlap, t_boxes, t_scores, fg, gt_idx);
   return (int)hipGetLastError();
 }
 

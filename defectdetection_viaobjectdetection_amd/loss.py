@@ -87,6 +87,27 @@ def assign_targets(scores: torch.Tensor, boxes: torch.Tensor, anchors_px: torch.
     return t_boxes, t_scores, fg, gt_idx
 
 
+@torch.no_grad()
+def _assign_targets_device(scores, boxes, anchors_px, gt_cls, gt_boxes, gt_valid):
+    """assign_targets on the device as two kernels (``m355_tal_assign_launch``): same outputs, ties of the top-10 broken towards the
+    lower anchor index."""
+    from ._capi import check, lib
+    B, A, nc = scores.shape
+    G = gt_boxes.shape[1]
+    dev = scores.device
+    sc, bx = scores.float().contiguous(), boxes.float().contiguous()
+    t_boxes = torch.zeros((B, A, 4), dtype=torch.float32, device=dev)
+    t_scores = torch.zeros((B, A, nc), dtype=torch.float32, device=dev)
+    fg = torch.zeros((B, A), dtype=torch.uint8, device=dev)
+    gt_idx = torch.zeros((B, A), dtype=torch.int64, device=dev)
+    ws = torch.empty(B * G * 10 * 3, dtype=torch.int32, device=dev)
+    check(lib.m355_tal_assign_launch(sc.data_ptr(), bx.data_ptr(), anchors_px.float().contiguous().data_ptr(),
+                                     gt_cls.to(torch.int32).contiguous().data_ptr(), gt_boxes.float().contiguous().data_ptr(),
+                                     gt_valid.to(torch.uint8).contiguous().data_ptr(), B, A, G, nc, ws.data_ptr(), t_boxes.data_ptr(),
+                                     t_scores.data_ptr(), fg.data_ptr(), gt_idx.data_ptr(), _stream()))
+    return t_boxes, t_scores, fg.bool(), gt_idx
+
+
 _CONST_CACHE: Dict = {}
 
 
@@ -249,7 +270,10 @@ def loss_core(raw: torch.Tensor, protos: torch.Tensor, gt_cls: torch.Tensor, gt_
             ltrb = (logits_box.view(B, A, 4, REG_MAX).softmax(3) * bins).sum(3)
             boxes_px = torch.cat((anchors - ltrb[..., :2], anchors + ltrb[..., 2:]), -1) * strides       # pixels
             scores = logits_cls.detach().sigmoid()
-    t_boxes, t_scores, fg, gt_idx = assign_targets(scores, boxes_px, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
+    if use_kernels and G > 0 and A <= 18000 and G <= 900:        # two launches instead of ~40 (csrc/loss_kernels.hip: tal_topk / tal_resolve)
+        t_boxes, t_scores, fg, gt_idx = _assign_targets_device(scores, boxes_px, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
+    else:
+        t_boxes, t_scores, fg, gt_idx = assign_targets(scores, boxes_px, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
     # Everything below runs over ALL anchors / a fixed number of slots per image with zero weights for the background,
     # so the step has no data-dependent shapes and no host synchronisation after the one that sized the GT padding.
     denom = t_scores.sum().clamp_min(1.0)

@@ -298,6 +298,14 @@ int m355_repack_launch(const m355_repack_job* d_jobs, const int32_t* d_block_job
 int m355_sppf_pool_bwd_launch(const void* a, int64_t a_bstride, int32_t lda, const void* y, int64_t y_bstride, int32_t ldy,
                               const void* gy, int64_t gy_bstride, int32_t ldgy, void* ga, int64_t ga_bstride, int32_t ldga,
                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t accumulate, void* stream);
+/* Task-aligned assignment of the training loss (csrc/loss_kernels.hip; upstream TaskAlignedAssigner: top-10 by score^0.5 * CIoU^6 among the
+ * anchors whose centre lies strictly inside the box, multiply-claimed anchors to the truth of highest CIoU, normalised alignment as
+ * target score).  All pointers device: scores (B,A,nc) f32, boxes (B,A,4) xyxy px, anchors_px (A,2), gt_cls (B,G) int32, gt_boxes (B,G,4),
+ * gt_valid (B,G) uint8; ws = 12 * B * G * 10 bytes of scratch; t_boxes (B,A,4), t_scores (B,A,nc), fg (B,A) uint8, gt_idx (B,A) int64 must
+ * be ZERO on entry (only the positives are written).  Asynchronous on `stream`. */
+int m355_tal_assign_launch(const float* scores, const float* boxes, const float* anchors_px, const int32_t* gt_cls, const float* gt_boxes,
+                           const uint8_t* gt_valid, int32_t B, int32_t A, int32_t G, int32_t nc, void* ws, float* t_boxes, float* t_scores,
+                           uint8_t* fg, int64_t* gt_idx, void* stream);
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 /* Gradient glue of the training step (each replaces a strided torch expression reached from yolo_seg_train.py:12's backward):

@@ -42,6 +42,36 @@ def test_loss_on_device_matches_oracle(seed, B, nc, imgsz, n_inst, empty, cuda_d
     np.testing.assert_allclose(gp.numpy(), gpo.numpy(), rtol=2e-3, atol=2e-6)
 
 
+@pytest.mark.parametrize("seed,B,nc,imgsz,n_inst", [(0, 8, 1, (320, 320), 3), (3, 4, 3, (160, 224), 6), (5, 16, 1, (640, 640), 2), (7, 2, 1, (160, 160), 0)])
+def test_tal_kernels_equal_the_torch_assignment(seed, B, nc, imgsz, n_inst, cuda_device):
+    """Task-aligned assignment as two HIP kernels (csrc/loss_kernels.hip: tal_topk / tal_resolve, m355_tal_assign_launch) against
+    loss.assign_targets (the torch restatement of upstream's TaskAlignedAssigner) on the same device tensors: the same foreground set,
+    assigned instance and target boxes, target scores to fp32 rounding.  Crowded cases (six overlapping instances per image) exercise
+    the multiply-claimed anchors."""
+    from defectdetection_viaobjectdetection_amd import loss as L
+    raw, _, batch, hw = _case(seed, B, nc, imgsz, max(n_inst, 1))
+    dev = cuda_device
+    A = raw.shape[1]
+    k = L._consts(imgsz, imgsz[0] // 4, imgsz[1] // 4, dev, (7.5, 0.5, 1.5))
+    r = raw.to(dev)
+    boxes, scores = L._decode_all(r, k["anchors"], k["strides_flat"], nc)
+    if n_inst == 0:
+        batch = {kk: (v[:0] if kk != "masks" else v) for kk, v in batch.items()}
+    gt_cls, gt_boxes, gt_valid = L.pad_targets({kk: v.to(dev) for kk, v in batch.items()}, B, imgsz, dev)
+    if gt_boxes.shape[1] == 0:
+        return                                                     # (no instance: loss_core takes the torch path)
+    want = L.assign_targets(scores, boxes, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
+    got = L._assign_targets_device(scores, boxes, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
+    torch.cuda.synchronize()
+    nfg = int(want[2].sum())
+    print(f"B={B} A={A} G={gt_boxes.shape[1]}: {nfg} foreground anchors")
+    assert nfg > 0
+    assert torch.equal(got[2], want[2])                                        # foreground mask
+    assert torch.equal(got[3][want[2]], want[3][want[2]])                      # assigned instance (on the foreground)
+    assert torch.equal(got[0][want[2]], want[0][want[2]])                      # target boxes
+    torch.testing.assert_close(got[1], want[1], rtol=1e-5, atol=1e-9)          # target scores (CIoU^6 as three multiplies vs torch.pow: a few ulp)
+
+
 def test_loss_on_the_train_engines_outputs(cuda_device):
     """The same comparison on real head maps: TrainEngine.forward -> loss on the device tensors it returned."""
     from defectdetection_viaobjectdetection_amd import loss as L

@@ -6,7 +6,7 @@ os.environ["M355_BNECK_REPS"] = "50"
 from defectdetection_viaobjectdetection_amd import _capi
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 h = lambda a: a.ctypes.data_as(C.c_void_p)
-for (H, W, ci, co, st) in ((20, 20, 256, 256, 1), (80, 80, 128, 256, 2), (40, 40, 256, 512, 2), (80, 80, 128, 128, 2), (40, 40, 256, 256, 2)):
+for (H, W, ci, co, st) in ((80, 80, 64, 64, 1), (40, 40, 128, 128, 1), (40, 40, 128, 64, 1), (40, 40, 64, 64, 1), (80, 80, 128, 128, 1), (80, 80, 128, 224, 1)):
     x = torch.randn(B, H, W, ci, device="cuda").half()
     y = torch.empty(B, H // st, W // st, co, device="cuda", dtype=torch.float16)
     w = (np.random.default_rng(0).standard_normal((co, ci, 3, 3)) * (2.0 / (9 * ci)) ** 0.5).astype(np.float32)
