@@ -377,9 +377,8 @@ __device__ __forceinline__ bool tal_cand(const float* g, float ax, float ay) {
   const float d = fminf(fminf(ax - g[0], ay - g[1]), fminf(g[2] - ax, g[3] - ay));
   return d > 1e-9f;
 }
-__device__ __forceinline__ float tal_metric(float score, float ov) {         // score^0.5 * ov^6 (ov >= 0)
-  const float o2 = ov * ov;
-  return sqrtf(score) * (o2 * o2 * o2);
+__device__ __forceinline__ float tal_metric(float score, float ov) {         // score^0.5 * ov^6 (ov >= 0): torch.pow(x, 0.5) is sqrt,
+  return sqrtf(score) * powf(ov, 6.0f);                                       // torch.pow(x, 6.0) the pow function -- the ORDER of the metrics decides
 }
 
 #pragma clang fp contract(off)

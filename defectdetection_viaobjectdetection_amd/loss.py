@@ -56,7 +56,7 @@ def ciou(b1: torch.Tensor, b2: torch.Tensor, complete: bool = True) -> torch.Ten
 @torch.no_grad()
 def assign_targets(scores: torch.Tensor, boxes: torch.Tensor, anchors_px: torch.Tensor, gt_cls: torch.Tensor,
                    gt_boxes: torch.Tensor, gt_valid: torch.Tensor, topk: int = 10, alpha: float = 0.5,
-                   beta: float = 6.0, eps: float = 1e-9):
+                   beta: float = 6.0, eps: float = 1e-9, stable_ties: bool = False):
     """Task-aligned assignment.  scores (B,A,nc) in [0,1]; boxes (B,A,4) xyxy px; anchors_px (A,2);
     gt_cls (B,G) long; gt_boxes (B,G,4) xyxy px; gt_valid (B,G) bool.
     Returns target boxes (B,A,4), target scores (B,A,nc), foreground mask (B,A), assigned GT index (B,A)."""
@@ -71,7 +71,14 @@ def assign_targets(scores: torch.Tensor, boxes: torch.Tensor, anchors_px: torch.
     overlap = ciou(gt_boxes[:, :, None, :], boxes[:, None, :, :]).clamp_min(0) * cand
     metric = (cls_score * cand).pow(alpha) * overlap.pow(beta)
     top = torch.zeros_like(cand)
-    top.scatter_(2, metric.topk(min(topk, A), dim=2).indices, True)
+    if stable_ties:
+        # torch.topk leaves the choice among EQUAL metrics unspecified; it matters when a truth has fewer than ten candidates with a
+        # positive metric (zero-metric candidates that make the top ten stay foreground).  This form fixes it the way the device
+        # kernels do (csrc/loss_kernels.hip: tal_topk_kernel): candidates before non-candidates, then the lower anchor index.
+        key = torch.where(cand, metric, torch.full_like(metric, -1.0))
+        top.scatter_(2, key.sort(dim=2, descending=True, stable=True).indices[..., :min(topk, A)], True)
+    else:
+        top.scatter_(2, metric.topk(min(topk, A), dim=2).indices, True)
     pos = top & cand
     claims = pos.sum(1)                                                          # several GTs -> highest overlap wins
     winner = torch.zeros_like(pos).scatter_(1, overlap.argmax(1, keepdim=True), True)
@@ -101,10 +108,12 @@ def _assign_targets_device(scores, boxes, anchors_px, gt_cls, gt_boxes, gt_valid
     fg = torch.zeros((B, A), dtype=torch.uint8, device=dev)
     gt_idx = torch.zeros((B, A), dtype=torch.int64, device=dev)
     ws = torch.empty(B * G * 10 * 3, dtype=torch.int32, device=dev)
-    check(lib.m355_tal_assign_launch(sc.data_ptr(), bx.data_ptr(), anchors_px.float().contiguous().data_ptr(),
-                                     gt_cls.to(torch.int32).contiguous().data_ptr(), gt_boxes.float().contiguous().data_ptr(),
-                                     gt_valid.to(torch.uint8).contiguous().data_ptr(), B, A, G, nc, ws.data_ptr(), t_boxes.data_ptr(),
-                                     t_scores.data_ptr(), fg.data_ptr(), gt_idx.data_ptr(), _stream()))
+    # the converted copies stay referenced until the launch is queued: a temporary inside the argument list is freed (and its block
+    # handed to the next conversion) as soon as its data_ptr() has been taken
+    anc, gc, gb, gv = (anchors_px.float().contiguous(), gt_cls.to(torch.int32).contiguous(), gt_boxes.float().contiguous(),
+                       gt_valid.to(torch.uint8).contiguous())
+    check(lib.m355_tal_assign_launch(sc.data_ptr(), bx.data_ptr(), anc.data_ptr(), gc.data_ptr(), gb.data_ptr(), gv.data_ptr(), B, A, G, nc,
+                                     ws.data_ptr(), t_boxes.data_ptr(), t_scores.data_ptr(), fg.data_ptr(), gt_idx.data_ptr(), _stream()))
     return t_boxes, t_scores, fg.bool(), gt_idx
 
 

@@ -578,7 +578,8 @@ class TrainEngine:
         x8 = self.tensors[self.x8]
         st = self._stream()
         # (u8 / 255) -> fp16 into the 8-channel input rows in one pass (was float(), div, half(), strided copy: 0.55 ms at b64)
-        check(lib.m355_u8_to_f16x8_launch(images_u8_nhwc.contiguous().data_ptr(), x8.data_ptr(), x8.numel() // 8, st))
+        src = images_u8_nhwc.contiguous()
+        check(lib.m355_u8_to_f16x8_launch(src.data_ptr(), x8.data_ptr(), x8.numel() // 8, st))
         side = self._head_stream
         if side is not None and self._head_ops is None and not any(o.get("name") == "model.15.cv2" for o in self.ops):
             side = self._head_stream = None                                 # (a graph without that fork point: one stream)

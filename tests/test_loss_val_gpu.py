@@ -60,7 +60,8 @@ def test_tal_kernels_equal_the_torch_assignment(seed, B, nc, imgsz, n_inst, cuda
     gt_cls, gt_boxes, gt_valid = L.pad_targets({kk: v.to(dev) for kk, v in batch.items()}, B, imgsz, dev)
     if gt_boxes.shape[1] == 0:
         return                                                     # (no instance: loss_core takes the torch path)
-    want = L.assign_targets(scores, boxes, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
+    # (stable_ties: torch.topk leaves ties among equal -- zero -- metrics unspecified; the kernels take candidates first, lower index first)
+    want = L.assign_targets(scores, boxes, k["anchors_px"], gt_cls, gt_boxes, gt_valid, stable_ties=True)
     got = L._assign_targets_device(scores, boxes, k["anchors_px"], gt_cls, gt_boxes, gt_valid)
     torch.cuda.synchronize()
     nfg = int(want[2].sum())
