@@ -145,8 +145,8 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       int pad_y = a.pad, pad_x = a.pad;
       if (KS == 2 && a.phase) {   // phase conv: the 2x2 window of phase (py, px) starts at (h - 1 + py, w - 1 + px)
         const int q = ch_base / a.convt_co;
-        pad_y = 1 - (q >> 1);
-        pad_x = 1 - (q & 1);
+        pad_y = a.phase == 2 ? 0 : 1 - (q >> 1);   // (phase == 2, the stride-2 dgrad: every phase's window starts at (h, w))
+        pad_x = a.phase == 2 ? 0 : 1 - (q & 1);
       }
       const int hi0 = ho * a.stride - pad_y;
       const int wi0 = wo * a.stride - pad_x;
@@ -619,7 +619,10 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       __syncthreads();                                   // (persistent mode: the stages are reused by the next tile)
       continue;
     }
-    if (KS == 2 && MT >= 2 && a.phase) {   // phase conv: pixel-shuffle store, bias by border class of the output pixel
+    // phase conv: pixel-shuffle store, bias by border class of the output pixel.  The stride-2 dgrad form (phase == 2) comes here
+    // only to accumulate into a gradient slice that already holds a consumer's contribution (a.res); without one it takes the
+    // ConvTranspose fast stores below, and with several phases per channel tile (convt_co < tile) the generic epilogue.
+    if (KS == 2 && MT >= 2 && a.phase && !(a.phase == 2 && (fast_t || a.convt_co % BCH))) {
       const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
       const int co = ch_base - q * a.convt_co + wch * MT * 16 + g * 8;
 #pragma unroll
@@ -631,17 +634,20 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
         fast_divmod(pix, a.Wo, inv_wo, ho, wo);
         const int Y = 2 * ho + dy, X = 2 * wo + dx;
         const int ry = Y == 0 ? 0 : (Y == 2 * a.Ho - 1 ? 2 : 1), rx = X == 0 ? 0 : (X == 2 * a.Wo - 1 ? 2 : 1);
-        const float* bp = a.bias + (ry * 3 + rx) * a.convt_co + co;
+        const float* bp = a.bias + (a.phase == 2 ? 0 : (ry * 3 + rx) * a.convt_co) + co;
         half_t* yp = (half_t*)a.y + (long)bb * a.y_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldy + co;
+        const half_t* rp = a.res ? a.res + (long)bb * a.r_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldr + co : nullptr;
 #pragma unroll
         for (int sg = 0; sg < MT / 2; ++sg) {
           if (co + sg * 32 >= a.convt_co) continue;
           const float4v b0 = *(const float4v*)(bp + sg * 32), b1 = *(const float4v*)(bp + sg * 32 + 4);
-          half8 o;
+          half8 o, rv;
+          if (rp) rv = *(const half8*)(rp + sg * 32);
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             float v0 = acc[2 * sg][nt][j] + b0[j], v1 = acc[(MT >= 2 ? 2 * sg + 1 : 0)][nt][j] + b1[j];
             if (a.act) { v0 = silu_f(v0); v1 = silu_f(v1); }
+            if (rp) { v0 += (float)rv[j]; v1 += (float)rv[4 + j]; }
             o[j] = m355_to_half(v0);
             o[4 + j] = m355_to_half(v1);
           }
@@ -899,7 +905,13 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   if (knobs().persist & (a.ksize == 1 ? 1 : 2)) a.dbg |= 64;
   if (a.ksize < 1 || a.ksize > 3) return -1;
   if (a.ksize == 2 && !a.phase && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // the ConvT-dgrad form ...
-  if (a.ksize == 2 && a.phase && (a.stride != 1 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 64)) return -1;  // ... or a phase conv
+  if (a.ksize == 2 && a.phase == 1 && (a.stride != 1 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 64)) return -1;  // ... or a phase conv
+  // ... or the dgrad of a 3x3 / stride-2 / pad-1 conv as four phase convs (phase == 2): x is dY, Cout = 4 * convt_co virtual channels
+  // (phase q = 2 * (row parity) + column parity of the dX pixel, then the forward input channel), 2x2 windows starting at (h, w)
+  if (a.ksize == 2 && a.phase == 2 && (a.stride != 1 || a.pad != 0 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 8 || a.w2 || a.act ||
+                                       a.Cout != 4 * a.convt_co))
+    return -1;
+  if (a.phase < 0 || a.phase > 2 || (a.phase && a.ksize != 2)) return -1;
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
   if (a.M >= (1 << 24)) return -1;  // fast_divmod range
   // the loader keeps row offsets as 32-bit counts of 8 elements: every stride a multiple of 8, the input within 2^34 elements
@@ -911,8 +923,14 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   int tile = force_tile & 0xff;
   if (force_tile < 0) tile = -1;
   if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
-  if (a.ksize == 2 && a.phase && ((tile == TILE_128x128 && a.convt_co % 128) || (tile != TILE_128x128 && tile != TILE_64x128)))
+  if (a.ksize == 2 && a.phase == 1 && ((tile == TILE_128x128 && a.convt_co % 128) || (tile != TILE_128x128 && tile != TILE_64x128)))
     return -1;   // a channel tile must lie inside one phase
+  if (a.ksize == 2 && a.phase == 2) {   // a tile inside one phase, or whole phases inside a tile (then no accumulation: generic epilogue)
+    if (force_tile < 0 && tile == TILE_128x128 && a.convt_co % 128 && a.convt_co % 64 == 0) tile = TILE_64x128;
+    const int bch = tile == TILE_128x128 ? 128 : 64;
+    if (tile != TILE_128x128 && tile != TILE_64x128) return -1;
+    if (a.convt_co % bch && (bch % a.convt_co || a.res)) return -1;
+  }
   if (a.w2 && a.phase && !(a.ksize == 2 && tile == TILE_128x128 && a.convt_co == 128 && a.cout2 == 32 && a.bias2)) return -1;
   if (a.dec_preds && !(a.ksize == 1 && a.out_f32 && tile == TILE_128x128 && a.Cout == 64 + a.dec_nc + a.dec_nm && a.Cout <= 128 &&
                        (a.Cout + 4 + a.dec_nc + a.dec_nm) * 64 * 4 <= 65536 && !a.res && a.convt_co == 0))

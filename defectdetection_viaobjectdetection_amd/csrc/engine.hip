@@ -901,7 +901,9 @@ void annotate_ops(m355_engine* e) {
         // owns a slab x 64 channels with its weights streamed to registers -- 21 us against 34 on 256 -> 256 at batch 32
         // ... and for the stride-2 3x3 convs that were on the im2col kernel (model.5 / 7 / 16 / 19 of the s scale: 177 us at batch 32)
         const bool planes_s2 = p.k == 3 && p.stride == 2 && op.res.t < 0 && op.in2.t < 0 && !op.s2c32 && !op.s2c64 && !getenv("M355_NO_PLANES_S2");
-        if (op.kind == OP_CONV && (op.tile == TILE_SLAB || planes_s2) && op.out_ext == 0 && p.l3 < 0 && !p.diag && !getenv("M355_NO_PLANES")) {
+        // ... and for the 64 -> 64 conv of the 40 x 40 level (model.22.cv2.1.1: 9 us against 14 on the 32x32x16 halo kernel)
+        const bool planes_m64 = m32 && cout_v <= 64 && op.res.t < 0 && op.in2.t < 0 && !getenv("M355_NO_PLANES_M64");
+        if (op.kind == OP_CONV && (op.tile == TILE_SLAB || planes_s2 || planes_m64) && op.out_ext == 0 && p.l3 < 0 && !p.diag && !getenv("M355_NO_PLANES")) {
           const Tensor& to2 = e->tensors[op.out.t];
           PlanesArgs pa{};
           pa.x = ti.p; pa.y = to2.p; pa.wfb = (const half_t*)1; pa.bb = (const float*)1;   // (shape check only)
@@ -1563,7 +1565,7 @@ int m355_forward(m355_engine* e, const void* d_in, int B, float* d_preds, void* 
           pa.wfb = p.wf; pa.cblocks_b = (p.cout + 63) / 64 * 2; pa.bb = p.bias; pa.act = p.act; pa.stride = p.stride;
           pa.y = (half_t*)a.y; pa.y_bstride = a.y_bstride; pa.ldy = a.ldy;
           pa.res = a.res; pa.r_bstride = a.r_bstride; pa.ldr = a.ldr;
-          rc = (p.wf && conv3x3_planes_ok(pa)) ? launch_conv3x3_planes(pa, s) : (p.stride == 1 ? launch_conv3x3_slab(a, s) : launch_conv_igemm(a, TILE_AUTO, s));
+          rc = (p.wf && conv3x3_planes_ok(pa)) ? launch_conv3x3_planes(pa, s) : (p.stride == 1 ? (conv3x3_slab_ok(a) ? launch_conv3x3_slab(a, s) : launch_conv3x3_halo(a, 0, s)) : launch_conv_igemm(a, TILE_AUTO, s));
           break;
         }
         rc = (op.s2c32 && conv_s2c32_cv1_ok(a)) ? launch_conv_s2c32_cv1(a, s)
@@ -2362,6 +2364,10 @@ int m355_conv_launch(const m355_conv_args* c, void* stream) {
   a.ksize = c->ksize; a.stride = c->stride; a.pad = c->pad; a.M = c->batch * c->ho * c->wo;
   a.act = c->act; a.out_f32 = c->out_f32; a.convt_co = c->convt_co; a.tmode = c->tmode;
   a.zero = (const half_t*)c->zero_page;
+  if (c->tmode == 2) {   // input gradient of a 3x3 / stride-2 / pad-1 conv as four 2x2 phase convs over dY (conv_igemm.hip, phase == 2)
+    a.tmode = 0;
+    a.phase = 2;
+  }
   int rc;
   // 1x1 convs of the training step (forward and input gradients) on conv1x1_wreg.hip where it applies (the weights are gathered
   // from the packed rows: the per-step re-pack writes no fragment-ordered copy): 27.4-27.5 -> 27.2-27.3 ms per s-seg b64 step on one box

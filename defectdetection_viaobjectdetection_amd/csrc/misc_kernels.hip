@@ -184,11 +184,13 @@ __device__ __forceinline__ half8 hmax8(half8 a, half8 b) {
 
 // CG 8-channel groups (CG * 16 bytes of a pixel) per block: consecutive lanes take consecutive groups of one pixel, so
 // a wave's loads / stores are runs of CG * 16 contiguous bytes.  Each 5x5 max is separable: a row pass into a scratch
-// plane, then a column pass; window indices are clamped (duplicates do not change a max), so both passes are five
+// plane, then a column pass; window indices are clamped (duplicates do not change a max), so both passes are four
 // unconditional LDS reads that the compiler unrolls and overlaps.
+//
+// Generic form (any plane size that fits the LDS): the (row, column) of an element is recomputed in every pass.
 template <int CG>
-__global__ __launch_bounds__(256) void sppf_pool_kernel(const half_t* x, long x_bstride, int ldx, half_t* y,
-                                                        long y_bstride, int ldy, int H, int W, int C) {
+__global__ __launch_bounds__(256) void sppf_pool_generic_kernel(const half_t* x, long x_bstride, int ldx, half_t* y,
+                                                                long y_bstride, int ldy, int H, int W, int C) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int n = H * W * CG;
   half8* src = (half8*)smem;
@@ -226,6 +228,82 @@ __global__ __launch_bounds__(256) void sppf_pool_kernel(const half_t* x, long x_
       *(half8*)(yb + (long)px * ldy + lvl * C + cgi * 8) = m;
     }
     __syncthreads();
+    half8* t = src;
+    src = dst;
+    dst = t;
+  }
+}
+
+// Planes of at most SPPF_NT * SPPF_ME elements (20 x 20 x 4 groups, 40 x 40 x 1): every thread owns the same <= SPPF_ME elements in
+// all six passes, so their (row, column) pairs are divided out once and the passes are clamp + ds_read_b128 + packed fp16 max.
+// The generic form spent its time there: two integer divisions and 40 scalar compare/select pairs per element per pass made the
+// 26 MB operation VALU-bound (25 us at batch 32; this form: see DESIGN.md section 9).
+constexpr int SPPF_ME = 4, SPPF_NT = 512;
+__device__ __forceinline__ int clampi(int v, int hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+// (a barrier that orders LDS traffic only: __syncthreads() would also drain the level's global stores before every pass)
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+}
+
+template <int CG>
+__global__ __launch_bounds__(SPPF_NT) void sppf_pool_kernel(const half_t* x, long x_bstride, int ldx, half_t* y,
+                                                            long y_bstride, int ldy, int H, int W, int C) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = H * W * CG, WC = W * CG;
+  half8* src = (half8*)smem;
+  half8* tmp = src + n;
+  half8* dst = tmp + n;
+  const int chunks = C / (8 * CG);
+  const int b = blockIdx.x / chunks, gq = blockIdx.x % chunks;
+  const half_t* xb = x + (long)b * x_bstride + gq * 8 * CG;
+  half_t* yb = y + (long)b * y_bstride + gq * 8 * CG;
+  // element slots past the plane alias its last element for the reads (no branch around them: the reads of all slots of a
+  // pass issue together) and skip the writes
+  int ei[SPPF_ME], dr[SPPF_ME][4], dc[SPPF_ME][4], yo[SPPF_ME];
+  bool on[SPPF_ME];
+#pragma unroll
+  for (int k = 0; k < SPPF_ME; ++k) {
+    const int i = threadIdx.x + SPPF_NT * k;
+    on[k] = i < n;
+    ei[k] = on[k] ? i : n - 1;
+    const int px = ei[k] / CG, h = px / W, w = px - h * W;
+    yo[k] = px * ldy + (ei[k] % CG) * 8;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int d = j < 2 ? j - 2 : j - 1;              // -2, -1, 1, 2
+      dr[k][j] = ei[k] + (clampi(w + d, W - 1) - w) * CG;
+      dc[k][j] = ei[k] + (clampi(h + d, H - 1) - h) * WC;
+    }
+    const half8 v = *(const half8*)(xb + (long)px * ldx + (ei[k] % CG) * 8);
+    if (on[k]) src[ei[k]] = v;
+  }
+  lds_barrier();
+  for (int lvl = 0; lvl < 3; ++lvl) {
+    half8 m[SPPF_ME];
+#pragma unroll
+    for (int k = 0; k < SPPF_ME; ++k) {
+      m[k] = src[ei[k]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[k] = __builtin_elementwise_max(m[k], src[dr[k][j]]);
+    }
+#pragma unroll
+    for (int k = 0; k < SPPF_ME; ++k)
+      if (on[k]) tmp[ei[k]] = m[k];
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < SPPF_ME; ++k) {
+      m[k] = tmp[ei[k]];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[k] = __builtin_elementwise_max(m[k], tmp[dc[k][j]]);
+    }
+#pragma unroll
+    for (int k = 0; k < SPPF_ME; ++k)
+      if (on[k]) {
+        dst[ei[k]] = m[k];
+        *(half8*)(yb + yo[k] + lvl * C) = m[k];
+      }
+    lds_barrier();
     half8* t = src;
     src = dst;
     dst = t;
@@ -371,17 +449,23 @@ int launch_stem(const StemArgs& a, hipStream_t s) {
 int launch_sppf_pool(const half_t* x, long x_bstride, int ldx, half_t* y, long y_bstride, int ldy, int B, int H,
                      int W, int C, hipStream_t s) {
   if (C % 8 || ldx % 8 || ldy % 8) return -1;
-  // widest channel chunk per block that still leaves >= 256 blocks and fits the LDS
+  // widest channel chunk per block that still leaves >= 256 blocks (one per CU) and fits the LDS; planes of at most 256 * SPPF_ME
+  // elements take the form with per-thread element ownership
+  static const int min_blocks = getenv("M355_SPPF_MINBLOCKS") ? atoi(getenv("M355_SPPF_MINBLOCKS")) : 256;
   int cg = 4;
-  while (cg > 1 && ((C / 8) % cg != 0 || (long)B * (C / (8 * cg)) < 512 || (size_t)3 * H * W * 16 * cg > 160 * 1024)) cg >>= 1;
+  while (cg > 1 && ((C / 8) % cg != 0 || (long)B * (C / (8 * cg)) < min_blocks || (size_t)3 * H * W * 16 * cg > 160 * 1024 ||
+                    H * W * cg > SPPF_NT * SPPF_ME))
+    cg >>= 1;
   const size_t lds = (size_t)3 * H * W * 16 * cg;
   if (lds > 160 * 1024) return -1;
-  auto k = cg == 4 ? sppf_pool_kernel<4> : (cg == 2 ? sppf_pool_kernel<2> : sppf_pool_kernel<1>);
+  const bool owned = H * W * cg <= SPPF_NT * SPPF_ME && (long)H * W * ldy < (1L << 30);
+  auto k = owned ? (cg == 4 ? sppf_pool_kernel<4> : (cg == 2 ? sppf_pool_kernel<2> : sppf_pool_kernel<1>))
+                 : (cg == 4 ? sppf_pool_generic_kernel<4> : (cg == 2 ? sppf_pool_generic_kernel<2> : sppf_pool_generic_kernel<1>));
   if (lds > 65536) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(k, dim3(B * (C / (8 * cg))), dim3(256), lds, s, x, x_bstride, ldx, y, y_bstride, ldy, H, W, C);
+  hipLaunchKernelGGL(k, dim3(B * (C / (8 * cg))), dim3(owned ? SPPF_NT : 256), lds, s, x, x_bstride, ldx, y, y_bstride, ldy, H, W, C);
   return (int)hipGetLastError();
 }
 

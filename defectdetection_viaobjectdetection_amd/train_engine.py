@@ -85,6 +85,9 @@ class TrainEngine:
             os_no_side = False
         self._wg_stream = None if (os_no_side or os.environ.get("M355_NO_WGRAD_STREAM") == "1") else torch.cuda.Stream(device=self.dev)
         self._wg_done = None                                                         # event after the last side-stream launch
+        # input gradients of the stride-2 3x3 convs as four phase convs over dY (16 tap slots for 9 taps) instead of the masked
+        # transposed-stride gather (36): M355_NO_DGRAD_PHASES=1 restores the gather (A/B and the parity test)
+        self._dgrad_phases = os.environ.get("M355_NO_DGRAD_PHASES") != "1"
         # forward: the 1/8-level head + the prototype branch beside the rest of the neck (M355_NO_HEAD_STREAM=1: one stream)
         self._head_stream = None if (os_no_side or os.environ.get("M355_NO_HEAD_STREAM") == "1") else torch.cuda.Stream(device=self.dev)
         self._head_ops = None
@@ -372,6 +375,18 @@ class TrainEngine:
             if s.cin != 3:                                                  # stride 2 = transposed-stride gather, no flip
                 out.append((self._pack_view(s.name + ":dgrad", cin_p, k * k * cout_p, (cin_p, k, k, cout_p))[..., :s.cout],
                             w.permute(3, 1, 2, 0), () if s.stride == 2 else (1, 2)))
+                if s.stride == 2 and k == 3 and self._dgrad_phases:
+                    # the same gradient as four 2x2 phase convs over dY (m355_conv_launch, tmode 2): rows [phase][ci], columns
+                    # [(ty, tx)][co]; dX row 2i (+0) takes tap kh = 1 from dY row i, row 2i + 1 takes kh = 2 from row i and kh = 0
+                    # from row i + 1 (columns alike); the seven unused tap slots of the sixteen stay zero from the allocation
+                    v = self._pack_view(s.name + ":dgrad4", 4 * cin_p, 4 * cout_p, (4, cin_p, 2, 2, cout_p))
+                    wt = w.permute(3, 1, 2, 0)                               # (cin, kh, kw, cout)
+                    taps = {0: ((0, 1),), 1: ((0, 2), (1, 0))}              # parity -> ((window slot, forward tap), ...)
+                    for a in (0, 1):
+                        for b in (0, 1):
+                            for ty, kh in taps[a]:
+                                for tx, kw in taps[b]:
+                                    out.append((v[2 * a + b, :, ty:ty + 1, tx:tx + 1, :s.cout], wt[:, kh:kh + 1, kw:kw + 1, :], ()))
         return out
 
     def _repack_torch(self) -> None:
@@ -712,9 +727,14 @@ class TrainEngine:
                                            s.stride, s.k // 2, gw)
                     gp, gbs, ldg = self._slice_ptr(self.gtensors, src)
                     acc = 0 if self._claim(written, src) else gp
-                    self._conv_launch(sv["dz"].data_ptr(), ho * wo * cout, cout, ho, wo, cout, self.packed[name + ":dgrad"],
-                                      gp, gbs, ldg, hi, wi, cin, s.k, 1, s.k // 2, res_ptr=acc, r_bs=gbs, ldr=ldg,
-                                      tmode=1 if s.stride == 2 else 0)
+                    if (s.stride == 2 and s.k == 3 and self._dgrad_phases and hi == 2 * ho and wi == 2 * wo
+                            and (cin % 64 == 0 or (128 % cin == 0 and not acc))):
+                        self._conv_launch(sv["dz"].data_ptr(), ho * wo * cout, cout, ho, wo, cout, self.packed[name + ":dgrad4"],
+                                          gp, gbs, ldg, ho, wo, 4 * cin, 2, 1, 0, res_ptr=acc, r_bs=gbs, ldr=ldg, convt_co=cin, tmode=2)
+                    else:
+                        self._conv_launch(sv["dz"].data_ptr(), ho * wo * cout, cout, ho, wo, cout, self.packed[name + ":dgrad"],
+                                          gp, gbs, ldg, hi, wi, cin, s.k, 1, s.k // 2, res_ptr=acc, r_bs=gbs, ldr=ldg,
+                                          tmode=1 if s.stride == 2 else 0)
             elif kind == "plain":
                 name, src = op["name"], op["src"]
                 s = self.specs[name]

@@ -250,7 +250,13 @@ typedef struct {
   int32_t act, out_f32, convt_co, tmode;
   const void* zero_page;                /* >= 16 zero bytes */
 } m355_conv_args;
-/* Convolution / dgrad / ConvTranspose forward on the implicit-GEMM or halo kernel (chosen by shape). */
+/* Convolution / dgrad / ConvTranspose forward on the implicit-GEMM or halo kernel (chosen by shape).
+ * tmode 1: input gradient of a 3x3 / stride-2 / pad-1 conv by a transposed-stride gather (x = dY, y = dX, all nine taps masked per
+ *          output parity; any size).
+ * tmode 2: the same gradient as FOUR 2x2 phase convs over dY (one per parity class of the dX pixel): ksize = 2, stride = 1, pad = 0,
+ *          hi x wi = ho x wo = the dY map, cout = 4 * convt_co virtual channels (phase-major), convt_co = the forward input channels,
+ *          y = the (2 ho) x (2 wo) dX slice, w_packed = [4 * convt_co][(ty, tx, forward cout)] with zero rows for the taps a phase does
+ *          not have (16 tap slots for 9 taps; tmode 1 multiplies 36).  Needs convt_co % 64 == 0, or 128 % convt_co == 0 and no res. */
 int m355_conv_launch(const m355_conv_args* a, void* stream);
 
 typedef struct {
