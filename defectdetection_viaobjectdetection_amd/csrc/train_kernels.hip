@@ -491,39 +491,64 @@ __global__ __launch_bounds__(256) void sppf_pool_bwd_kernel(const half_t* a, lon
 #pragma unroll
     for (int j = 0; j < 8; ++j) rout[i * 8 + j] = (float)g3[j];
   }
+  // work item = (pixel, four of the eight channels): every LDS access of the two window walks is 8 or 16 bytes wide.  (One channel per
+  // item, 2-byte reads: 150 scalar LDS reads per element and stage made this 26 MB operation 460 us of a 25 ms step.)
+  typedef unsigned short ushort4v __attribute__((ext_vector_type(4)));
+  const int items = H * W * 2;
   for (int stage = 2; stage >= 0; --stage) {
     const half_t* src = stage == 2 ? yb + C : (stage == 1 ? yb : ab);       // y2, y1, a
     const int lds_ = stage == 0 ? lda : ldy;
     for (int i = threadIdx.x; i < H * W; i += 256) *(half8*)(v + i * 8) = *(const half8*)(src + (long)i * lds_);
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += 256) {             // argmax of the window centred on pixel q
-      const int q = e >> 3, ch = e & 7;
+    for (int e = threadIdx.x; e < items; e += 256) {         // argmax of the window centred on pixel q (first maximum, row-major)
+      const int q = e >> 1, h4 = (e & 1) * 4;
       const int qy = q / W, qx = q - qy * W;
-      const int y0 = qy - 2 < 0 ? 0 : qy - 2, y1 = qy + 2 >= H ? H - 1 : qy + 2;
-      const int x0 = qx - 2 < 0 ? 0 : qx - 2, x1 = qx + 2 >= W ? W - 1 : qx + 2;
-      float best = -INFINITY;
-      int bi = y0 * W + x0;
-      for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) {
-          const float t = (float)v[(yy * W + xx) * 8 + ch];
-          if (t > best) { best = t; bi = yy * W + xx; }
+      float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      const int first = (qy - 2 < 0 ? 0 : qy - 2) * W + (qx - 2 < 0 ? 0 : qx - 2);
+      int bi[4] = {first, first, first, first};
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = qy + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int xx = qx + dx;
+          if (xx < 0 || xx >= W) continue;
+          const half4 t = *(const half4*)(v + (yy * W + xx) * 8 + h4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((float)t[j] > best[j]) { best[j] = (float)t[j]; bi[j] = yy * W + xx; }
         }
-      idx[e] = (unsigned short)bi;
+      }
+      *(ushort4v*)(idx + q * 8 + h4) = ushort4v{(unsigned short)bi[0], (unsigned short)bi[1], (unsigned short)bi[2], (unsigned short)bi[3]};
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < n; e += 256) {             // gather
-      const int p = e >> 3, ch = e & 7;
+    for (int e = threadIdx.x; e < items; e += 256) {         // gather, windows in ascending (row, column) order
+      const int p = e >> 1, h4 = (e & 1) * 4;
       const int py = p / W, px = p - py * W;
-      const int y0 = py - 2 < 0 ? 0 : py - 2, y1 = py + 2 >= H ? H - 1 : py + 2;
-      const int x0 = px - 2 < 0 ? 0 : px - 2, x1 = px + 2 >= W ? W - 1 : px + 2;
-      float sum = 0.f;
-      for (int yy = y0; yy <= y1; ++yy)
-        for (int xx = x0; xx <= x1; ++xx) {
+      float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dy = -2; dy <= 2; ++dy) {
+        const int yy = py + dy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int dx = -2; dx <= 2; ++dx) {
+          const int xx = px + dx;
+          if (xx < 0 || xx >= W) continue;
           const int q = yy * W + xx;
-          if (idx[q * 8 + ch] == (unsigned short)p) sum += rout[q * 8 + ch];
+          const ushort4v id = *(const ushort4v*)(idx + q * 8 + h4);
+          const float4v r = *(const float4v*)(rout + q * 8 + h4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (id[j] == (unsigned short)p) sum[j] += r[j];
         }
-      if (stage > 0) sum += (float)gb[(long)p * ldgy + (stage - 1) * C + ch];   // the map's own slot in the concat: y2 (stage 2), y1 (stage 1)
-      rin[e] = sum;
+      }
+      if (stage > 0) {   // the map's own slot in the concat: y2 (stage 2), y1 (stage 1)
+        const half4 g = *(const half4*)(gb + (long)p * ldgy + (stage - 1) * C + h4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum[j] += (float)g[j];
+      }
+      *(float4v*)(rin + p * 8 + h4) = float4v{sum[0], sum[1], sum[2], sum[3]};
     }
     __syncthreads();
     float* t = rout; rout = rin; rin = t;
