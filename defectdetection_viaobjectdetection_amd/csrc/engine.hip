@@ -2196,15 +2196,25 @@ int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const floa
   const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
   // dgrad as a conv with "output channels" = cin and K = (tap, cout): row ci, column (tap', co)
   //   stride 1: tap' = flipped tap (kh' = k-1-kh);  stride 2 (transposed-stride gather): tap' = tap
-  const int cout_pad = conv_cout_pad(cin);
-  const int Kpad = conv_kpad(cout, k);
+  // stride 2 on even maps: four 2x2 phase convs over dY (conv_igemm.hip, phase == 2) -- rows [phase][ci], columns [(ty, tx)][co];
+  // dX row 2i takes tap kh = 1 from dY row i, row 2i + 1 takes kh = 2 from row i and kh = 0 from row i + 1 (columns alike)
+  const bool phases = stride == 2 && k == 3 && H == 2 * Ho && W == 2 * Wo && (cin % 64 == 0 || 128 % cin == 0) &&
+                      !getenv("M355_NO_DGRAD_PHASES");
+  const int cout_pad = conv_cout_pad(phases ? 4 * cin : cin);
+  const int Kpad = phases ? conv_kpad(cout, 2) : conv_kpad(cout, k);
   std::vector<half_t> rows((size_t)cout_pad * Kpad, (half_t)0.f);
   for (int co = 0; co < cout; ++co)
     for (int ci = 0; ci < cin; ++ci)
       for (int kh = 0; kh < k; ++kh)
         for (int kw = 0; kw < k; ++kw) {
-          const int t = (stride == 1) ? ((k - 1 - kh) * k + (k - 1 - kw)) : (kh * k + kw);
-          rows[(size_t)ci * Kpad + (size_t)t * cout + co] = (half_t)h_w[(((size_t)co * cin + ci) * k + kh) * k + kw];
+          const half_t v = (half_t)h_w[(((size_t)co * cin + ci) * k + kh) * k + kw];
+          if (phases) {
+            const int pa = kh == 1 ? 0 : 1, ty = kh == 0 ? 1 : 0, pb = kw == 1 ? 0 : 1, tx = kw == 0 ? 1 : 0;
+            rows[(size_t)((2 * pa + pb) * cin + ci) * Kpad + (size_t)(ty * 2 + tx) * cout + co] = v;
+          } else {
+            const int t = (stride == 1) ? ((k - 1 - kh) * k + (k - 1 - kw)) : (kh * k + kw);
+            rows[(size_t)ci * Kpad + (size_t)t * cout + co] = v;
+          }
         }
   std::vector<float> bias(cout_pad, 0.f);
   half_t *dw = nullptr, *dz = nullptr;
@@ -2221,8 +2231,12 @@ int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const floa
   a.y = d_dx; a.y_bstride = (long)H * W * cin; a.ldy = cin; a.Ho = H; a.Wo = W; a.Cout = cin;
   a.ksize = k; a.stride = 1; a.pad = pad; a.tmode = (stride == 2) ? 1 : 0;
   a.M = B * H * W;
+  if (phases) {
+    a.Ho = Ho; a.Wo = Wo; a.Cout = 4 * cin; a.convt_co = cin; a.ksize = 2; a.pad = 0; a.tmode = 0; a.phase = 2;
+    a.M = B * Ho * Wo;
+  }
   int rc;
-  if (!a.tmode && conv3x3_halo_ok(a))
+  if (!a.tmode && !a.phase && conv3x3_halo_ok(a))
     rc = launch_conv3x3_halo(a, 0, s);
   else
     rc = launch_conv_igemm(a, TILE_AUTO, s);

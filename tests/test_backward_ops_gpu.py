@@ -26,9 +26,12 @@ DGRAD_CASES = [
     (2, 16, 16, 64, 64, 3, 1),       # halo path
     (2, 20, 24, 32, 64, 3, 1),       # im2col path (Cin of the dgrad GEMM = cout = 64, output channels 32)
     (2, 16, 16, 128, 64, 1, 1),
-    (2, 32, 32, 64, 128, 3, 2),      # transposed-stride gather
-    (1, 34, 22, 32, 64, 3, 2),       # odd output sizes (17 x 11)
+    (2, 32, 32, 64, 128, 3, 2),      # stride 2 on even maps: four phase convs over dY, pixel-shuffle fast stores (Wo % 16 == 0)
+    (1, 34, 22, 32, 64, 3, 2),       # the same with four phases per channel tile (cin 32) and odd dY sizes (17 x 11): generic epilogue
     (3, 40, 40, 128, 256, 3, 2),
+    (2, 64, 64, 32, 64, 3, 2),       # cin 32, full tiles
+    (2, 33, 21, 64, 128, 3, 2),      # odd input sizes: the transposed-stride gather (all nine taps masked per output parity)
+    (1, 48, 80, 256, 512, 3, 2),
 ]
 
 
@@ -49,6 +52,26 @@ def test_conv2d_dgrad(case, cuda_device):
     got = d_dx.float().cpu().permute(0, 3, 1, 2)
     assert torch.isfinite(got).all()
     assert rel_l2(got, x.grad) <= 1e-3
+
+
+def test_stride2_dgrad_phase_form_equals_the_gather_form(cuda_device, monkeypatch):
+    """A/B of the two stride-2 input-gradient forms on the same operands: the same nine products per output in fp32, so the results
+    agree to fp16 rounding of sums taken in a different order."""
+    from defectdetection_viaobjectdetection_amd import _capi
+    B, H, W, cin, cout = 2, 40, 48, 128, 256
+    g = torch.Generator().manual_seed(5)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).half().float().contiguous()
+    d_dy = nhwc16(torch.randn(B, cout, H // 2, W // 2, generator=g), cuda_device)
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("M355_NO_DGRAD_PHASES", "1")
+        d_dx = torch.full((B, H, W, cin), float("nan"), dtype=torch.float16, device=cuda_device)
+        _capi.check(_capi.lib.m355_conv2d_dgrad(_p(d_dy), B, H, W, cin, _p(w), cout, 3, 2, _p(d_dx),
+                                                C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        outs.append(d_dx.float().cpu())
+    assert torch.isfinite(outs[0]).all()
+    assert rel_l2(outs[0], outs[1]) <= 5e-4
 
 
 @pytest.mark.parametrize("shape,act", [((4, 20, 20, 64), 1), ((2, 40, 24, 128), 1), ((3, 16, 16, 48), 1), ((2, 8, 8, 512), 0)])
