@@ -656,6 +656,32 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       }
       continue;
     }
+    // stride-2 dgrad with 32 forward input channels (phase == 2, convt_co == 32): every 32-channel group of the tile is one phase of
+    // the same 32 dX channels.  Whole tiles only; the generic epilogue below did this with two divisions per group at 0.74 TB/s.
+    if (KS == 2 && MT >= 2 && a.phase == 2 && a.convt_co == 32 && !a.out_f32 && !a.res && !a.act && px_base + BPX <= a.M &&
+        ch_base + BCH <= a.Cout && !(a.dbg & (32 | 256))) {
+      const float4v b0 = *(const float4v*)(a.bias + g * 8), b1 = *(const float4v*)(a.bias + g * 8 + 4);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int m = px_base + wpx * NT * 16 + nt * 16 + l15;
+        int bb, pix, ho, wo;
+        fast_divmod(m, HoWo, inv_howo, bb, pix);
+        fast_divmod(pix, a.Wo, inv_wo, ho, wo);
+        half_t* const yb = (half_t*)a.y + (long)bb * a.y_bstride + ((long)(2 * ho) * (2 * a.Wo) + 2 * wo) * a.ldy + g * 8;
+#pragma unroll
+        for (int sg = 0; sg < MT / 2; ++sg) {
+          const int q = (ch_base + wch * MT * 16 + sg * 32) >> 5;
+          half8 o;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = m355_to_half(acc[2 * sg][nt][j] + b0[j]);
+            o[4 + j] = m355_to_half(acc[(MT >= 2 ? 2 * sg + 1 : 0)][nt][j] + b1[j]);
+          }
+          *(half8*)(yb + ((long)(q >> 1) * (2 * a.Wo) + (q & 1)) * a.ldy) = o;
+        }
+      }
+      continue;
+    }
     if (MT >= 2 && fast_t) {
       const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
       const int co = ch_base - q * a.convt_co + wch * MT * 16 + g * 8;
