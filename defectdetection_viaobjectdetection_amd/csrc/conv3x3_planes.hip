@@ -26,11 +26,19 @@
 // GEMM orientation as in conv3x3_m32.hip: D[channel][pixel], weights = A operand, rows permuted on the DMA source side so
 // that a lane-half owns 16 consecutive channels of its pixel (two 16-byte stores / LDS writes per pixel block).
 //
-// Block = 4 waves, one per SIMD (up to 512 VGPRs; the 64-channel instance: 8 waves, two per SIMD): wave = (channel block wc of WC,
-// pixel group wp of WP = waves / WC), NPB pixel blocks each (accumulators: 16 x NPB VGPRs).  K loop: phase = one input plane (32 channels), step =
-// one tap = 2 MFMA slices of K = 16.  Weight ring of four stages: the stage of step g + 3 is issued in step g, a step waits
-// (counted vmcnt) for the stage of step g + 1 only.  Input planes: ring of two; the pieces of plane p + 1 are issued during
-// the first six steps of phase p.  ONE barrier per step.
+// Block = 4 waves, one per SIMD (up to 512 VGPRs): wave = (channel block wc of WC, pixel group wp of WP = 4 / WC), NPB pixel blocks
+// each (accumulators: 16 x NPB VGPRs).  K loop: PHASE = one input plane (32 channels) = 9 taps x 2 MFMA slices of K = 16 for every
+// pixel block of the wave, pixel-block-major (the 18 MFMAs of a block back to back on one accumulator).
+//   * WEIGHTS never touch LDS: the host packs them as MFMA A fragments in K-loop order [channel block][plane][tap][slice] (1 KiB
+//     each, lane-linear: planes_frag_pack in engine.hip) and a wave loads the 18 fragments of the NEXT phase straight into its A
+//     registers through a per-phase buffer descriptor, each right after its last use in the current phase; they are L2 hits for all
+//     blocks but the first.  No weight stage, no weight barrier, no ds_read for the A operand.
+//   * B fragments (activations) come from the plane by ds_read_b128 through a register FIFO of FQ = 9 slots, FD = 8 reads in flight.
+//   * Input planes: ring of two; the pieces of plane p + 1 are issued by LDS-DMA during phase p (PIT pieces per wave).  ONE barrier
+//     per phase, behind a counted s_waitcnt (the weight loads issued after the pieces stay in flight across it).
+//   * The VALU work of a finished pixel block (bias is the C operand of the first phase; SiLU, fp16, residual, stores / LDS writes
+//     of the hidden tensor) runs as a software pipeline, one stage per MFMA slot of the following block (PostPipe), so a dependent
+//     chain never stalls the wave that also feeds the matrix pipe.
 #include <stdlib.h>
 
 #include <algorithm>
