@@ -12,9 +12,16 @@
 // transposition buffer.
 //
 // Block = 8 waves, one block per CU, CB = Cout / 32 channel blocks per tile (4 or 8).  Every wave = one channel block x
-// 64 pixels (two 32-pixel MFMA blocks): CB = 8 -> tile = 64 pixels, wave = channel block; CB = 4 -> tile = 128 pixels,
-// wave = (channel block, pixel half).  Cout = 512 runs as two channel tiles of 256.  Pixels are the flattened (image, row,
-// column) index: a 1x1 convolution has no halo.
+// PB 32-pixel MFMA blocks (PB = 2: 64 pixels): CB = 8 -> tile = 64 pixels, wave = channel block; CB = 4 -> tile = 128 pixels,
+// wave = (channel block, pixel half); CB = 4, PB = 1 (K = 384: a 128-pixel tile of 768-byte rows does not fit two buffers) ->
+// tile = 64 pixels.  Cout = 512 runs as two channel tiles of 256.  Pixels are the flattened (image, row, column) index: a 1x1
+// convolution has no halo.
+//
+// SPLIT (round 4; model.15.cv1 of the s scale: Upsample + Concat + C2f.cv1): the first `csplit` channels of a pixel come from a
+// tensor of half the resolution, pixel (h >> 1, w >> 1) -- nn.Upsample(scale_factor=2, 'nearest') read through instead of
+// materialised -- and the rest from x at their own channel offset.  An LDS-DMA instruction takes ONE buffer descriptor, so the
+// tile is kept as two images (256 read-through channels per pixel, then 128 own channels per pixel): every 1 KiB piece has one
+// source.
 //
 // LDS image: one row of K fp16 per pixel; the low bits of the 16-byte chunk index are XOR-ed with the pixel index (4 bits
 // when K % 128 == 0, else 3) on the DMA source side and on the reads, so the 32 lanes of a fragment read (32 pixels, same
@@ -52,12 +59,13 @@ __device__ __forceinline__ void silu16(float16v& v) {
   for (int j = 0; j < 16; ++j) v[j] = v[j] * t[j];
 }
 
-template <int K, int CB>
+template <int K, int CB, int PB = 2>
 struct W1 {
   static constexpr int KS = K / 16;                    // K slices
   static constexpr int NCH = K / 8;                    // 16-byte chunks per pixel row
   static constexpr int RB = 2 * K;                     // bytes per pixel row
-  static constexpr int TP = 64 * (8 / CB);             // pixels per tile
+  static constexpr int TP = 32 * PB * (8 / CB);        // pixels per tile
+  static constexpr int WPX = 32 * PB;                  // pixels per wave
   static constexpr int TILE_BYTES = TP * RB;
   static constexpr int NPIECES = TILE_BYTES / 1024;
   static constexpr int P_IT = NPIECES / NWAVES;
@@ -70,13 +78,21 @@ struct W1 {
   static constexpr int STG_OFF = NBUF * TILE_BYTES;    // 8 waves x 32 pixels x 64 bytes (one pixel block at a time)
   static constexpr int BIAS_OFF = STG_OFF + NWAVES * 2048;
   static constexpr int LDS_BYTES = BIAS_OFF + 1024;
-  static_assert(K % 64 == 0 && K <= 512 && (CB == 4 || CB == 8) && NPIECES % NWAVES == 0, "shape");
+  static_assert(K % 64 == 0 && K <= 512 && (CB == 4 || CB == 8) && (PB == 1 || PB == 2) && NPIECES % NWAVES == 0, "shape");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS");
 };
 
-template <int K, int CB>
+__device__ __forceinline__ void fdivmod(int n, int d, float inv_d, int& q, int& r) {   // 0 <= n < 2^24 (as in conv_igemm.hip)
+  q = (int)((float)n * inv_d);
+  r = n - q * d;
+  if (r < 0) { r += d; --q; }
+  if (r >= d) { r -= d; ++q; }
+}
+
+template <int K, int CB, int PB, bool SPLIT>
 __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, int ntiles_px, int ntiles) {
-  using C = W1<K, CB>;
+  using C = W1<K, CB, PB>;
+  static_assert(!SPLIT || (K == 384 && CB == 4 && PB == 1 && C::SWM == 15 && C::SWS == 0), "the split form: 256 read-through + 128 own channels");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -108,6 +124,10 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
   };
 
   const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)((long)a.M * a.ldx * 2), 0x00020000);
+  const int HW = a.Ho * a.Wo;
+  const __amdgpu_buffer_rsrc_t rs_x2 = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(SPLIT ? a.x2 : a.x), 0, SPLIT ? (int)((long)(a.M / HW) * a.x2_bstride * 2) : 0, 0x00020000);
+  const float inv_hw = 1.0f / (float)HW, inv_w = 1.0f / (float)a.Wo;
   // ---- activation tile pieces: wave w owns pieces g = w + 8 i; lane-linear chunk id c = 64 g + lane = (pixel, slot)
   // (the per-piece offsets are rebuilt from mbcnt at every issue: held in registers across the K loop they are spilled in the
   // K = 512 form, and a scratch reload waits on vmcnt(0), i.e. on the stores of the tile just finished)
@@ -121,16 +141,35 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
       const int cid = 64 * (wave + NWAVES * i) + ln;
       const int px = cid / C::NCH, slot = cid - px * C::NCH;
       const int cc = slot ^ ((px >> C::SWS) & C::SWM);
-      dma16(rs_x, px < npx ? (px * a.ldx + cc * 8) * 2 : (int)0x80000000, soff,
-            smem + buf * C::TILE_BYTES + (wave + NWAVES * i) * 1024);   // past the tensor: zeros
+      char* const dst = smem + buf * C::TILE_BYTES + (wave + NWAVES * i) * 1024;
+      if constexpr (SPLIT) {
+        // the tile as TWO images, [pixel][256 low-resolution channels] then [pixel][128 channels of x]: pieces 0 .. 31 belong to the
+        // first, 32 .. 47 to the second, so a piece has ONE source (a piece of the interleaved row format holds chunks of both: two
+        // masked instructions per piece made the launch DMA-issue-bound, 49.6 us)
+        const int g = wave + NWAVES * i;               // (i < 4: low image, compile-time per i)
+        if (i < 4) {
+          const int c2 = 64 * g + ln, px2 = c2 >> 5, slot2 = c2 & 31;
+          const int cc2 = (slot2 & ~15) | ((slot2 ^ px2) & 15);
+          int b, pix, ho, wo;
+          fdivmod(p0 + (px2 < npx ? px2 : 0), HW, inv_hw, b, pix);
+          fdivmod(pix, a.Wo, inv_w, ho, wo);
+          dma16(rs_x2, px2 < npx ? (int)(((long)b * a.x2_bstride + ((long)(ho >> 1) * (a.Wo >> 1) + (wo >> 1)) * a.ldx2 + cc2 * 8) * 2)
+                                 : (int)0x80000000, 0, dst);
+        } else {
+          const int c2 = 64 * (g - 32) + ln, px2 = c2 >> 4, slot2 = c2 & 15;
+          dma16(rs_x, px2 < npx ? (px2 * a.ldx + 256 + ((slot2 ^ px2) & 15) * 8) * 2 : (int)0x80000000, soff, dst);
+        }
+      } else {
+        dma16(rs_x, px < npx ? (px * a.ldx + cc * 8) * 2 : (int)0x80000000, soff, dst);   // past the tensor: zeros
+      }
     }
   };
-  // ---- fragment offsets: pixel (64 ph + 32 pb + n) of the tile, chunk 2 s + h
-  int offp[2], swz[2];
+  // ---- fragment offsets: pixel (WPX ph + 32 pb + n) of the tile, chunk 2 s + h
+  int offp[PB], swz[PB];
 #pragma unroll
-  for (int pb = 0; pb < 2; ++pb) {
-    const int px = 64 * ph + 32 * pb + n;
-    offp[pb] = px * C::RB;
+  for (int pb = 0; pb < PB; ++pb) {
+    const int px = C::WPX * ph + 32 * pb + n;
+    offp[pb] = SPLIT ? px * 512 : px * C::RB;            // (SPLIT: offset in the low image; the other image: TP * 512 + px * 256)
     swz[pb] = (px >> C::SWS) & C::SWM;
   }
   // output staging: this wave's 64 pixels x 32 channels (64-byte rows); chunk XOR (pixel >> 1) & 3
@@ -161,7 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
       }
     }
     const char* const xb = smem + (it % C::NBUF) * C::TILE_BYTES;
-    float16v acc[2];
+    float16v acc[PB];
     {
       float16v bv;
 #pragma unroll
@@ -169,17 +208,21 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
         const float4v u = *(const float4v*)(smem + C::BIAS_OFF + (32 * m + 16 * h + 4 * qd) * 4);
         bv[qd * 4 + 0] = u[0]; bv[qd * 4 + 1] = u[1]; bv[qd * 4 + 2] = u[2]; bv[qd * 4 + 3] = u[3];
       }
-      acc[0] = bv; acc[1] = bv;
+#pragma unroll
+      for (int pb = 0; pb < PB; ++pb) acc[pb] = bv;
     }
     // ---- K loop in groups of four slices; the fragments of group g + 1 are read under the MFMAs of group g
-    half8 fr[2][2][4];
+    half8 fr[2][PB][4];
     auto read_group = [&](int g, int set) __attribute__((always_inline)) {
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb)
+      for (int pb = 0; pb < PB; ++pb)
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
           const int ch = 2 * (4 * g + s) + h;
-          fr[set][pb][s] = *(const half8*)(xb + offp[pb] + (((ch & ~C::SWM) | ((ch ^ swz[pb]) & C::SWM)) << 4));
+          if (SPLIT && 4 * g + s >= 16)      // channels 256 .. 383: the second image (256-byte rows)
+            fr[set][pb][s] = *(const half8*)(xb + C::TP * 512 + (offp[pb] >> 1) + ((((ch - 32) ^ swz[pb]) & 15) << 4));
+          else
+            fr[set][pb][s] = *(const half8*)(xb + offp[pb] + (((ch & ~C::SWM) | ((ch ^ swz[pb]) & C::SWM)) << 4));
         }
     };
     read_group(0, 0);
@@ -189,15 +232,15 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
+        for (int pb = 0; pb < PB; ++pb)
           acc[pb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wv[4 * g + s], fr[g & 1][pb][s], acc[pb], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
     }
     // ---- epilogue, one pixel block at a time: SiLU, fp16, transpose through 2 KB of LDS, 64-byte row segments out
     {
-      half_t* const yb = (half_t*)a.y + (long)(p0 + 64 * ph) * a.ldy + ct * CB * 32 + 32 * m;
+      half_t* const yb = (half_t*)a.y + (long)(p0 + C::WPX * ph) * a.ldy + ct * CB * 32 + 32 * m;
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb) {
+      for (int pb = 0; pb < PB; ++pb) {
         if (a.act) silu16(acc[pb]);
         half8 o0, o1;
 #pragma unroll
@@ -213,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
         for (int i = 0; i < 2; ++i) {
           const int p = 16 * i + st_p;
           const half8 v = *(const half8*)(stg + p * 64 + ((st_k ^ ((p >> 1) & 3)) << 4));
-          if (p0 + 64 * ph + 32 * pb + p < a.M) *(half8*)(yb + (long)(32 * pb + p) * a.ldy + st_k * 8) = v;
+          if (p0 + C::WPX * ph + 32 * pb + p < a.M) *(half8*)(yb + (long)(32 * pb + p) * a.ldy + st_k * 8) = v;
         }
       }
     }
@@ -226,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
       if (partial) {
         if (have2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::P_IT) : "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      } else if (have2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::P_IT + 4) : "memory");
-      else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+      } else if (have2) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(C::P_IT + 2 * PB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * PB) : "memory");
       __builtin_amdgcn_s_barrier();
     } else {
       // two buffers: every wave is done reading this tile -> issue the tile after next into it, then wait for the next tile
@@ -256,13 +299,13 @@ __global__ __launch_bounds__(512, 2) void conv1x1_wreg_kernel(const ConvArgs a, 
   }
 }
 
-template <int K, int CB>
+template <int K, int CB, int PB = 2, bool SPLIT = false>
 int launch_w1(const ConvArgs& a, hipStream_t s) {
-  using C = W1<K, CB>;
+  using C = W1<K, CB, PB>;
   const int ntiles_px = (a.M + C::TP - 1) / C::TP, ctiles = a.Cout / (CB * 32);   // (the last pixel tile may be partial)
   const int ntiles = ntiles_px * ctiles;
   static int slots = 0;
-  auto k = conv1x1_wreg_kernel<K, CB>;
+  auto k = conv1x1_wreg_kernel<K, CB, PB, SPLIT>;
   if (!slots) {
     hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES);
     if (e != hipSuccess) return (int)e;
@@ -280,10 +323,11 @@ int launch_w1(const ConvArgs& a, hipStream_t s) {
 
 }  // namespace
 
-// Eligibility: 1x1 / s1, fp16 in and out, no residual / read-through / fused epilogue, dense pixel rows (the batch is one
-// flat pixel axis), K in {128, 192, 256, 384, 512}, Cout a multiple of 128; any pixel count (a partial last pixel tile is masked).
+// Eligibility: 1x1 / s1, fp16 in and out, no residual / fused epilogue, dense pixel rows (the batch is one flat pixel axis), K in
+// {128, 192, 256, 384, 512}, Cout a multiple of 128; any pixel count (a partial last pixel tile is masked).  The upsample
+// read-through (csplit) only in the 384 -> 128 form.
 bool conv1x1_wreg_ok(const ConvArgs& a) {
-  if (a.ksize != 1 || a.stride != 1 || a.pad != 0 || a.out_f32 || a.convt_co > 0 || a.tmode || a.phase || a.csplit || a.w2 || a.dec_preds ||
+  if (a.ksize != 1 || a.stride != 1 || a.pad != 0 || a.out_f32 || a.convt_co > 0 || a.tmode || a.phase || a.w2 || a.dec_preds ||
       a.res)
     return false;
   if (a.Cin != 128 && a.Cin != 192 && a.Cin != 256 && a.Cin != 384 && a.Cin != 512) return false;
@@ -291,18 +335,27 @@ bool conv1x1_wreg_ok(const ConvArgs& a) {
   if (a.Ho != a.Hi || a.Wo != a.Wi) return false;
   if (a.x_bstride != (long)a.Hi * a.Wi * a.ldx || a.y_bstride != (long)a.Ho * a.Wo * a.ldy) return false;   // flat pixel axis
   const int cb = a.Cout % 256 == 0 ? 8 : 4;
-  if (cb == 4 && a.Cin > 256) return false;              // (a 128-pixel tile of K > 256 does not fit two LDS buffers)
+  if (cb == 4 && a.Cin > 384) return false;              // (a 64-pixel tile of K = 512 leaves the 128-channel form no second buffer worth having)
+  if (a.csplit > 0) {
+    // upsample read-through: the 384 -> 128 instance only; the low-resolution part in whole 16-chunk groups (the piece accounting of
+    // the kernel), even maps, every pixel of x2 reachable through one buffer descriptor, pixel count within the float divide
+    if (!(a.Cin == 384 && cb == 4) || !a.x2 || a.csplit != 256 || a.ldx2 % 8 || a.x2_bstride % 8 || (a.Hi & 1) ||
+        (a.Wi & 1) || a.M >= (1 << 24) || a.M % ((long)a.Ho * a.Wo))
+      return false;
+    if ((a.M / ((long)a.Ho * a.Wo)) * a.x2_bstride * 2 >= (1L << 31)) return false;
+  }
   return (long)a.M * a.ldx * 2 < (1L << 31) && (long)a.M * a.ldy < (1L << 31);
 }
 
 int launch_conv1x1_wreg(const ConvArgs& a, hipStream_t s) {
   if (!conv1x1_wreg_ok(a) || !conv_rows_covered(a, 128)) return -1;
   const bool c8 = a.Cout % 256 == 0;
+  if (a.csplit > 0 && !(a.Cin == 384 && !c8)) return -1;
   switch (a.Cin) {
     case 128: return c8 ? launch_w1<128, 8>(a, s) : launch_w1<128, 4>(a, s);
     case 192: return c8 ? launch_w1<192, 8>(a, s) : launch_w1<192, 4>(a, s);
     case 256: return c8 ? launch_w1<256, 8>(a, s) : launch_w1<256, 4>(a, s);
-    case 384: return c8 ? launch_w1<384, 8>(a, s) : -1;
+    case 384: return c8 ? launch_w1<384, 8>(a, s) : (a.csplit > 0 ? launch_w1<384, 4, 1, true>(a, s) : launch_w1<384, 4, 1, false>(a, s));
     case 512: return c8 ? launch_w1<512, 8>(a, s) : -1;
   }
   return -1;

@@ -887,10 +887,15 @@ void annotate_ops(m355_engine* e) {
             ConvArgs pr2 = probe;
             pr2.ldx = ti.C; pr2.ldy = 8; pr2.Kpad = p.Kpad; pr2.M = e->desc.max_batch * Ho * Wo; pr2.x_bstride = (long)ti.H * ti.W * ti.C;
             // 1x1 with K <= 512 and Cout a multiple of 128: weights in registers (conv1x1_wreg.hip)
-            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !p.diag && op.in2.t < 0 && op.res.t < 0 && !op.decode) {
+            if (op.kind == OP_CONV && op.out_ext == 0 && p.l3 < 0 && !p.diag && op.res.t < 0 && !op.decode &&
+                (op.in2.t < 0 || !getenv("M355_NO_W1_SPLIT"))) {
               ConvArgs pr3 = pr2;
               const Tensor& to2 = e->tensors[op.out.t];
               pr3.ldy = to2.C; pr3.y_bstride = (long)to2.H * to2.W * to2.C;
+              if (op.in2.t >= 0) {   // Upsample + Concat read through (model.15.cv1 of the s scale: 384 -> 128)
+                const Tensor& t2 = e->tensors[op.in2.t];
+                pr3.x2 = t2.p + op.in2.off; pr3.x2_bstride = (long)t2.H * t2.W * t2.C; pr3.ldx2 = t2.C; pr3.csplit = op.in2.c;
+              }
               if (conv1x1_wreg_ok(pr3) && !getenv("M355_NO_W1")) op.tile = TILE_W1;
             }
           }

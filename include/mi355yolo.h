@@ -134,6 +134,9 @@ int m355_postprocess(m355_engine* e, const float* d_preds, const void* d_protos,
  *   M355_PAIR64=1       also use the pair launch for 64-channel bottlenecks (measured no gain: off)
  *   M355_NO_PLANES      the 20 x 20 level on conv3x3_slab instead of the row-slab kernel
  *   M355_NO_C2F32       model.2 as three launches instead of c2f_c32
+ *   M355_NO_W1_SPLIT    model.15.cv1 (Upsample + Concat read through) on the im2col kernel instead of conv1x1_wreg's split form
+ *   M355_NO_PLANES_S2, M355_NO_PLANES_M64   the stride-2 3x3 convs / the 64 -> 64 conv of the 40 x 40 head level off the row-slab kernel
+ *   M355_NO_DGRAD_PHASES  (training) stride-2 input gradients as the masked nine-tap gather instead of four phase convs
  *   M355_NO_W1, M355_NO_S2C64, M355_NO_S2C32, M355_NO_PROTOR, M355_NO_PROTOFUSE(3), M355_NO_HEADTAIL, M355_NO_STEMFUSE,
  *   M355_NO_STEM2, M355_NO_CVFUSE, M355_NO_UPFUSE, M355_NO_C32, M355_NO_M32, M355_NO_WIDE, M355_NO_HALO, M355_NO_SLAB,
  *   M355_DECFUSE=1      each falls back from one fused / specialised kernel to the kernels it replaced (names = file names in csrc/)
@@ -196,7 +199,8 @@ int m355_head_tail_fwd(const void* d_x_f16_nhwc, int B, int H, int W, int nc, fl
                        void* stream);
 /* Data gradient of Conv2d(k in {1,3}, stride in {1,2}, pad k/2, no bias) (SURVEY A13 backward): dY fp16 NHWC
  * (B,Ho,Wo,cout) -> dX fp16 NHWC (B,H,W,cin).  Runs on the same implicit-GEMM kernel: stride 1 = convolution
- * with the spatially flipped, channel-transposed weights; stride 2 = transposed-stride gather.  h_w is the
+ * with the spatially flipped, channel-transposed weights; stride 2 = four 2x2 phase convs over dY on even maps (tmode 2 of
+ * m355_conv_launch), the masked transposed-stride gather otherwise (or with M355_NO_DGRAD_PHASES=1).  h_w is the
  * FORWARD weight fp32 (cout,cin,k,k) on the host.                                                   [sync] */
 int m355_conv2d_dgrad(const void* d_dy_f16_nhwc, int B, int H, int W, int cin, const float* h_w, int cout, int k,
                       int stride, void* d_dx_f16_nhwc, void* stream);

@@ -146,6 +146,7 @@ def test_weights_in_registers_kernels_equal_the_im2col_forms(cuda_device, size, 
         outs[name] = (preds.clone(), protos.float().clone())
         eng.close()
     assert any(k.startswith("conv1x1_wreg") for k in kern["default"])
+    assert "conv1x1_wreg<K384,128ch>" in kern["default"]      # model.15.cv1: Upsample + Concat read through by the weights-in-registers kernel (round 4)
     assert not any(k.startswith(("conv1x1_wreg", "proto_phase_wreg", "c2f_c32", "conv3x3_s2c64", "bneck_pair", "conv3x3_planes")) for k in kern["old"])
     assert any(k.startswith("bneck_pair<128ch>") for k in kern["default"]) and any(k.startswith("conv3x3_planes") for k in kern["default"])
     assert any(k.startswith("bneck_pair<64ch>") for k in kern["all"]) and not any(k.startswith("bneck_pair<64ch>") for k in kern["default"])
