@@ -235,6 +235,13 @@ size_t bn_workspace_floats(int C);
 // gradient glue of the training step (train_kernels.hip): fixed-order column sums, nearest-2x upsample backward, input conversion
 long colsum_workspace_floats(long nb, int cols);
 int launch_colsum(const void* src, int src_f16, long nb, long bstride, long rows, int ld, int cols, float* ws, float* out, hipStream_t s);
+// YOLOv9c training glue (train_kernels.hip): RepConvN's SiLU(a + b) and ADown's pooling front, forward and backward
+int launch_addsilu_fwd(const half_t* a, const half_t* b, half_t* v, half_t* y, long npix, int ldy, int C, hipStream_t s);
+int launch_addsilu_bwd(const half_t* v, const half_t* dy, int lddy, half_t* g, long npix, int C, hipStream_t s);
+int launch_adown_fwd(const half_t* x, long x_bs, int ldx, half_t* p1, long p1_bs, int ld1, half_t* p2, long p2_bs, int ld2, unsigned char* arg,
+                     int B, int H, int W, int c, hipStream_t s);
+int launch_adown_bwd(const half_t* g1, long g1_bs, int ld1, const half_t* g2, long g2_bs, int ld2, const unsigned char* arg, half_t* gx,
+                     long gx_bs, int ldg, int B, int H, int W, int c, int accumulate, hipStream_t s);
 int launch_upsample2x_bwd(const half_t* g, long g_bs, int ldg, half_t* d, long d_bs, int ldd, int B, int H, int W, int C, int accumulate,
                           hipStream_t s);
 int launch_u8_to_f16x8(const unsigned char* src, half_t* dst, long npx, hipStream_t s);

@@ -2520,6 +2520,31 @@ int m355_upsample2x_bwd_launch(const void* g, int64_t g_bstride, int32_t ldg, vo
   return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "upsample backward launch failed: " + std::to_string(rc));
 }
 
+int m355_addsilu_fwd_launch(const void* a, const void* b, void* v, void* y, int64_t npix, int32_t ldy, int32_t C, void* stream) {
+  const int rc = launch_addsilu_fwd((const half_t*)a, (const half_t*)b, (half_t*)v, (half_t*)y, npix, ldy, C, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "addsilu forward launch failed: " + std::to_string(rc));
+}
+
+int m355_addsilu_bwd_launch(const void* v, const void* dy, int32_t lddy, void* g, int64_t npix, int32_t C, void* stream) {
+  const int rc = launch_addsilu_bwd((const half_t*)v, (const half_t*)dy, lddy, (half_t*)g, npix, C, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "addsilu backward launch failed: " + std::to_string(rc));
+}
+
+int m355_adown_fwd_launch(const void* x, int64_t x_bstride, int32_t ldx, void* p1, int64_t p1_bstride, int32_t ld1, void* p2,
+                          int64_t p2_bstride, int32_t ld2, uint8_t* argmax, int32_t B, int32_t H, int32_t W, int32_t c, void* stream) {
+  const int rc = launch_adown_fwd((const half_t*)x, x_bstride, ldx, (half_t*)p1, p1_bstride, ld1, (half_t*)p2, p2_bstride, ld2, argmax, B, H, W, c,
+                                  (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "adown forward launch failed: " + std::to_string(rc));
+}
+
+int m355_adown_bwd_launch(const void* g1, int64_t g1_bstride, int32_t ld1, const void* g2, int64_t g2_bstride, int32_t ld2,
+                          const uint8_t* argmax, void* gx, int64_t gx_bstride, int32_t ldg, int32_t B, int32_t H, int32_t W, int32_t c,
+                          int32_t accumulate, void* stream) {
+  const int rc = launch_adown_bwd((const half_t*)g1, g1_bstride, ld1, (const half_t*)g2, g2_bstride, ld2, argmax, (half_t*)gx, gx_bstride, ldg, B,
+                                  H, W, c, accumulate, (hipStream_t)stream);
+  return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "adown backward launch failed: " + std::to_string(rc));
+}
+
 int m355_u8_to_f16x8_launch(const uint8_t* src, void* dst, int64_t npx, void* stream) {
   const int rc = launch_u8_to_f16x8(src, (half_t*)dst, npx, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(rc == -1 ? M355_ERR_INVALID : M355_ERR_HIP, "input conversion launch failed: " + std::to_string(rc));

@@ -750,6 +750,221 @@ __global__ __launch_bounds__(256) void u8_to_f16x8_kernel(const unsigned char* s
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// YOLOv9c training glue (the graph /root/reference/BscanBased/yolo_seg_train.py:7 names).  Two ops of that graph
+// have no convolution in them and ran as torch expressions on fp32 NCHW copies until round 4:
+//   RepConvN's tail        y = SiLU(a + b) of the two activation-free Conv + BN branches (upstream RepConvN.forward: act(conv1(x) + conv2(x)))
+//   ADown's pooling front  t = avg_pool2d(x, 2, 1, 0);  p1 = t[:, :c];  p2 = max_pool2d(t[:, c:], 3, 2, 1)   (upstream ADown.forward)
+// Forward and backward of each as one pass over NHWC fp16 rows, a thread per (pixel, 8-channel group).  The arithmetic keeps the
+// rounding points of the torch form: v = fp16(a + b) is stored for the backward; averages are fp32 sums x 0.25 rounded to fp16 once;
+// the max-pool's argmax (first maximum in row-major window order, torch's rule) is stored as one byte per element by the forward
+// pass, so the backward is a GATHER in a fixed order: no atomics, bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void addsilu_fwd_kernel(const half_t* a, const half_t* b, half_t* v, half_t* y, long npix, int ldy, int C,
+                                                          long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int cg = C / 8;
+  const long p = e / cg;
+  const int c8 = (int)(e - p * cg) * 8;
+  const half8 va = *(const half8*)(a + p * C + c8), vb = *(const half8*)(b + p * C + c8);
+  half8 s, o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s[j] = m355_to_half((float)va[j] + (float)vb[j]);
+    const float f = (float)s[j];
+    o[j] = m355_to_half(f * sigmoid_f(f));
+  }
+  *(half8*)(v + p * C + c8) = s;
+  *(half8*)(y + p * ldy + c8) = o;
+}
+
+// g = dy * SiLU'(v): ONE buffer, the gradient of both branches
+__global__ __launch_bounds__(256) void addsilu_bwd_kernel(const half_t* v, const half_t* dy, int lddy, half_t* g, int C, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int cg = C / 8;
+  const long p = e / cg;
+  const int c8 = (int)(e - p * cg) * 8;
+  const half8 vv = *(const half8*)(v + p * C + c8), d = *(const half8*)(dy + p * lddy + c8);
+  half8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float f = (float)vv[j], sg = sigmoid_f(f);
+    o[j] = m355_to_half((float)d[j] * (sg * (1.0f + f * (1.0f - sg))));
+  }
+  *(half8*)(g + p * C + c8) = o;
+}
+
+__device__ __forceinline__ void avg4(const half_t* x, long row, int ldx, float (&t)[8]) {   // 2x2 average at (y, x): rows y, y + 1
+  const half8 a = *(const half8*)x, b = *(const half8*)(x + ldx), c = *(const half8*)(x + row), d = *(const half8*)(x + row + ldx);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) t[j] = ((((float)a[j] + (float)b[j]) + (float)c[j]) + (float)d[j]) * 0.25f;
+}
+
+// x (B,H,W,>=2c) -> p1 (B,H-1,W-1,c) = 2x2/s1 average of channels [0,c);  p2 (B,Ho,Wo,c) = 3x3/s2/p1 max of the averages of
+// channels [c,2c), Ho = (H-2)/2+1;  arg (B,Ho,Wo,c) uint8: window position 3*ky+kx of the maximum.  Work items: the p1 elements
+// first, then the p2 elements.
+__global__ __launch_bounds__(256) void adown_fwd_kernel(const half_t* x, long x_bs, int ldx, half_t* p1, long p1_bs, int ld1, half_t* p2,
+                                                        long p2_bs, int ld2, unsigned char* arg, int H, int W, int Ho, int Wo, int c,
+                                                        long n1, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int cg = c / 8;
+  const long row = (long)W * ldx;
+  if (e < n1) {
+    const int c8 = (int)(e % cg) * 8;
+    long r = e / cg;
+    const int xx = (int)(r % (W - 1));
+    r /= (W - 1);
+    const int yy = (int)(r % (H - 1));
+    const long b = r / (H - 1);
+    float t[8];
+    avg4(x + b * x_bs + ((long)yy * W + xx) * ldx + c8, row, ldx, t);
+    half8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = m355_to_half(t[j]);
+    *(half8*)(p1 + b * p1_bs + ((long)yy * (W - 1) + xx) * ld1 + c8) = o;
+    return;
+  }
+  const long e2 = e - n1;
+  const int c8 = (int)(e2 % cg) * 8;
+  long r = e2 / cg;
+  const int xo = (int)(r % Wo);
+  r /= Wo;
+  const int yo = (int)(r % Ho);
+  const long b = r / Ho;
+  float best[8];
+  int bi[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { best[j] = -INFINITY; bi[j] = 0; }
+  bool first = true;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int yy = 2 * yo - 1 + ky;
+    if (yy < 0 || yy >= H - 1) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int xx = 2 * xo - 1 + kx;
+      if (xx < 0 || xx >= W - 1) continue;
+      float t[8];
+      avg4(x + b * x_bs + ((long)yy * W + xx) * ldx + c + c8, row, ldx, t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (first || t[j] > best[j]) { best[j] = t[j]; bi[j] = 3 * ky + kx; }
+      first = false;
+    }
+  }
+  half8 o;
+  unsigned long long packed = 0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    o[j] = m355_to_half(best[j]);
+    packed |= (unsigned long long)bi[j] << (8 * j);
+  }
+  const long po = ((long)yo * Wo + xo);
+  *(half8*)(p2 + b * p2_bs + po * ld2 + c8) = o;
+  *(unsigned long long*)(arg + ((b * Ho * Wo + po) * c + c8)) = packed;
+}
+
+// gx (B,H,W,>=2c): channels [0,c): 0.25 x the sum of the <= 4 gradients g1 of the averages that contain the pixel; channels [c,2c):
+// the same over ga, where ga(y', x') = sum of g2 over the <= 4 pooling windows whose stored argmax is (y', x') -- gathered window by
+// window in ascending (yo, xo) order.  accumulate: gx += fp16(result) (fp32 add, one rounding: the arithmetic of Tensor.add_).
+__global__ __launch_bounds__(256) void adown_bwd_kernel(const half_t* g1, long g1_bs, int ld1, const half_t* g2, long g2_bs, int ld2,
+                                                        const unsigned char* arg, half_t* gx, long gx_bs, int ldg, int H, int W, int Ho, int Wo,
+                                                        int c, int accumulate, long total) {
+  const long e = (long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  const int cg2 = 2 * c / 8;
+  const int c8 = (int)(e % cg2) * 8;
+  long r = e / cg2;
+  const int xx = (int)(r % W);
+  r /= W;
+  const int yy = (int)(r % H);
+  const long b = r / H;
+  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dy = 1; dy >= 0; --dy) {           // averages (y', x') = (yy - dy, xx - dx) in ascending order
+    const int ya = yy - dy;
+    if (ya < 0 || ya >= H - 1) continue;
+#pragma unroll
+    for (int dx = 1; dx >= 0; --dx) {
+      const int xa = xx - dx;
+      if (xa < 0 || xa >= W - 1) continue;
+      if (c8 < c) {
+        const half8 g = *(const half8*)(g1 + b * g1_bs + ((long)ya * (W - 1) + xa) * ld1 + c8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] += (float)g[j];
+      } else {
+        // pooling windows that contain (ya, xa): yo with 2 yo - 1 <= ya <= 2 yo + 1
+        const int yo0 = ya >> 1, yo1 = (ya + 1) >> 1, xo0 = xa >> 1, xo1 = (xa + 1) >> 1;
+        for (int yo = yo0; yo <= yo1; ++yo) {
+          if (yo >= Ho) continue;
+          for (int xo = xo0; xo <= xo1; ++xo) {
+            if (xo >= Wo) continue;
+            const int pos = 3 * (ya - (2 * yo - 1)) + (xa - (2 * xo - 1));
+            const long po = (long)yo * Wo + xo;
+            const unsigned long long id = *(const unsigned long long*)(arg + ((b * Ho * Wo + po) * c + (c8 - c)));
+            const half8 g = *(const half8*)(g2 + b * g2_bs + po * ld2 + (c8 - c));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if ((int)((id >> (8 * j)) & 0xff) == pos) sum[j] += (float)g[j];
+          }
+        }
+      }
+    }
+  }
+  half_t* const gp = gx + b * gx_bs + ((long)yy * W + xx) * ldg + c8;
+  half8 o;
+  if (accumulate) {
+    const half8 old = *(const half8*)gp;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = m355_to_half((float)old[j] + (float)m355_to_half(sum[j] * 0.25f));
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = m355_to_half(sum[j] * 0.25f);
+  }
+  *(half8*)gp = o;
+}
+
+}  // namespace
+
+int launch_addsilu_fwd(const half_t* a, const half_t* b, half_t* v, half_t* y, long npix, int ldy, int C, hipStream_t s) {
+  if (!a || !b || !v || !y || npix < 1 || C < 8 || C % 8 || ldy % 8 || ldy < C) return -1;
+  const long total = npix * (C / 8);
+  hipLaunchKernelGGL(addsilu_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, b, v, y, npix, ldy, C, total);
+  return (int)hipGetLastError();
+}
+
+int launch_addsilu_bwd(const half_t* v, const half_t* dy, int lddy, half_t* g, long npix, int C, hipStream_t s) {
+  if (!v || !dy || !g || npix < 1 || C < 8 || C % 8 || lddy % 8 || lddy < C) return -1;
+  const long total = npix * (C / 8);
+  hipLaunchKernelGGL(addsilu_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, v, dy, lddy, g, C, total);
+  return (int)hipGetLastError();
+}
+
+int launch_adown_fwd(const half_t* x, long x_bs, int ldx, half_t* p1, long p1_bs, int ld1, half_t* p2, long p2_bs, int ld2, unsigned char* arg,
+                     int B, int H, int W, int c, hipStream_t s) {
+  if (!x || !p1 || !p2 || !arg || B < 1 || H < 2 || W < 2 || c < 8 || c % 8 || ldx % 8 || ld1 % 8 || ld2 % 8 || ldx < 2 * c) return -1;
+  const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
+  const long n1 = (long)B * (H - 1) * (W - 1) * (c / 8), total = n1 + (long)B * Ho * Wo * (c / 8);
+  hipLaunchKernelGGL(adown_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x_bs, ldx, p1, p1_bs, ld1, p2, p2_bs, ld2, arg,
+                     H, W, Ho, Wo, c, n1, total);
+  return (int)hipGetLastError();
+}
+
+int launch_adown_bwd(const half_t* g1, long g1_bs, int ld1, const half_t* g2, long g2_bs, int ld2, const unsigned char* arg, half_t* gx,
+                     long gx_bs, int ldg, int B, int H, int W, int c, int accumulate, hipStream_t s) {
+  if (!g1 || !g2 || !arg || !gx || B < 1 || H < 2 || W < 2 || c < 8 || c % 8 || ld1 % 8 || ld2 % 8 || ldg % 8 || ldg < 2 * c) return -1;
+  const int Ho = (H - 2) / 2 + 1, Wo = (W - 2) / 2 + 1;
+  const long total = (long)B * H * W * (2 * c / 8);
+  hipLaunchKernelGGL(adown_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g1, g1_bs, ld1, g2, g2_bs, ld2, arg, gx, gx_bs, ldg,
+                     H, W, Ho, Wo, c, accumulate, total);
+  return (int)hipGetLastError();
+}
+
 long colsum_workspace_floats(long nb, int cols) { return WS_HEAD + (nb > CS_BLOCKS ? nb : (long)CS_BLOCKS) * cols; }
 
 // out[c] = sum over (b, r) of src[b * bstride + r * ld + c], c < cols, in a fixed order (partial rows + bn_finalize_kernel).

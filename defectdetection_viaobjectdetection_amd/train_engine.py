@@ -564,22 +564,30 @@ class TrainEngine:
             yp, ybs, ldy = self._slice_ptr(self.tensors, dst)
             check(lib.m355_upsample2x_launch(xp, xbs, ldx, yp, ybs, ldy, B, H, W, src.c, st))
         elif kind == "addsilu":
-            # RepConvN's tail: SiLU(a + b) of the two activation-free branches.  Byte-moving elementwise glue (torch): the
-            # FLOP-carrying parts -- both convolutions, both batch-norms -- ran in the HIP kernels just before.
-            a, b, dst = self._tview(op["a"]), self._tview(op["b"]), self._tview(op["dst"])
+            # RepConvN's tail: SiLU(a + b) of the two activation-free branches, one pass (csrc/train_kernels.hip: addsilu_fwd_kernel);
+            # v = fp16(a + b) is kept for the backward pass
+            a, b, dst = op["a"], op["b"], op["dst"]
+            ta, tb = self.tensors[a.t], self.tensors[b.t]
             v = op.get("_v")
             if v is None:
-                v = op["_v"] = torch.empty(a.shape, dtype=torch.float16, device=self.dev)
-            torch.add(a, b, out=v)                                           # kept for the backward pass (fp16 like every activation)
-            dst.copy_(F.silu(v.float()))
+                v = op["_v"] = torch.empty(ta.shape, dtype=torch.float16, device=self.dev)
+            assert a.off == 0 and b.off == 0 and ta.shape[3] == a.c and tb.shape[3] == b.c
+            yp, _, ldy = self._slice_ptr(self.tensors, dst)
+            check(lib.m355_addsilu_fwd_launch(ta.data_ptr(), tb.data_ptr(), v.data_ptr(), yp, ta.shape[0] * ta.shape[1] * ta.shape[2], ldy, a.c, st))
         elif kind == "adown":
-            # ADown's pooling front (2x2 average at stride 1, channel split, 3x3 / s2 max-pool of the second half): pooling
-            # glue on torch, its two convolutions follow as ordinary conv ops
-            x = self._tview(op["src"]).permute(0, 3, 1, 2)
-            c = op["src"].c // 2
-            a = F.avg_pool2d(x.float(), 2, 1, 0)
-            self._tview(op["p1"]).copy_(a[:, :c].permute(0, 2, 3, 1))
-            self._tview(op["p2"]).copy_(F.max_pool2d(a[:, c:], 3, 2, 1).permute(0, 2, 3, 1))
+            # ADown's pooling front (2x2 average at stride 1, channel split, 3x3 / s2 max-pool of the second half) as one launch
+            # (adown_fwd_kernel; the max-pool's argmax goes to a byte map for the backward); its two convolutions follow as conv ops
+            src, p1, p2 = op["src"], op["p1"], op["p2"]
+            _, H, W, _ = self.tensors[src.t].shape
+            c = src.c // 2
+            arg = op.get("_arg")
+            if arg is None:
+                arg = op["_arg"] = torch.empty((B, H // 2, W // 2, c), dtype=torch.uint8, device=self.dev)
+            assert (H - 2) // 2 + 1 == H // 2 and (W - 2) // 2 + 1 == W // 2
+            xp, xbs, ldx = self._slice_ptr(self.tensors, src)
+            p1p, p1bs, ld1 = self._slice_ptr(self.tensors, p1)
+            p2p, p2bs, ld2 = self._slice_ptr(self.tensors, p2)
+            check(lib.m355_adown_fwd_launch(xp, xbs, ldx, p1p, p1bs, ld1, p2p, p2bs, ld2, arg.data_ptr(), B, H, W, c, st))
 
     def _tview(self, sl: Slice) -> torch.Tensor:
         return self.tensors[sl.t][..., sl.off:sl.off + sl.c]
@@ -817,24 +825,21 @@ class TrainEngine:
             elif kind == "addsilu":                                        # y = SiLU(v), v = a + b: dv = dy * SiLU'(v) for BOTH branches
                 a_, b_, dst = op["a"], op["b"], op["dst"]
                 self._ensure(written, dst)
-                v = op["_v"].float()
-                sig = torch.sigmoid(v)
-                self.gtensors[a_.t].copy_(self._gview(dst).float() * (sig * (1.0 + v * (1.0 - sig))))
+                gyp, _, ldgy = self._slice_ptr(self.gtensors, dst)
+                g = self.gtensors[a_.t]
+                check(lib.m355_addsilu_bwd_launch(op["_v"].data_ptr(), gyp, ldgy, g.data_ptr(), g.shape[0] * g.shape[1] * g.shape[2], a_.c, st))
                 written[a_.t] = [(0, a_.c)]
                 written[b_.t] = [(0, b_.c)]                                 # (the same buffer: galias)
-            elif kind == "adown":                                          # pooling backward through autograd on fp32 NCHW copies
+            elif kind == "adown":                                          # gather backward of the pooling front (adown_bwd_kernel)
                 src, p1, p2 = op["src"], op["p1"], op["p2"]
                 self._ensure(written, p1)
                 self._ensure(written, p2)
-                c = src.c // 2
-                x = self._tview(src).permute(0, 3, 1, 2).float().contiguous().requires_grad_(True)
-                a = F.avg_pool2d(x, 2, 1, 0)
-                y1, y2 = a[:, :c], F.max_pool2d(a[:, c:], 3, 2, 1)
-                (gx,) = torch.autograd.grad((y1, y2), x, (self._gview(p1).permute(0, 3, 1, 2).float(), self._gview(p2).permute(0, 3, 1, 2).float()))
-                if self._claim(written, src):
-                    self._gview(src).copy_(gx.permute(0, 2, 3, 1))
-                else:
-                    self._gview(src).add_(gx.permute(0, 2, 3, 1).half())
+                _, H, W, _ = self.tensors[src.t].shape
+                g1p, g1bs, ld1 = self._slice_ptr(self.gtensors, p1)
+                g2p, g2bs, ld2 = self._slice_ptr(self.gtensors, p2)
+                gxp, gxbs, ldg = self._slice_ptr(self.gtensors, src)
+                check(lib.m355_adown_bwd_launch(g1p, g1bs, ld1, g2p, g2bs, ld2, op["_arg"].data_ptr(), gxp, gxbs, ldg, B, H, W, src.c // 2,
+                                                0 if self._claim(written, src) else 1, st))
             elif kind == "up":
                 src, dst = op["src"], op["dst"]
                 self._ensure(written, dst)

@@ -316,6 +316,21 @@ int m355_sppf_pool_bwd_launch(const void* a, int64_t a_bstride, int32_t lda, con
 int m355_tal_assign_launch(const float* scores, const float* boxes, const float* anchors_px, const int32_t* gt_cls, const float* gt_boxes,
                            const uint8_t* gt_valid, int32_t B, int32_t A, int32_t G, int32_t nc, void* ws, float* t_boxes, float* t_scores,
                            uint8_t* fg, int64_t* gt_idx, void* stream);
+/* YOLOv9c training glue (csrc/train_kernels.hip; the graph /root/reference/BscanBased/yolo_seg_train.py:7 names), fp16 NHWC, asynchronous:
+ *  addsilu: RepConvN's tail  y = SiLU(a + b)  of its two activation-free Conv + BN branches (upstream RepConvN.forward).  a, b, v, g are
+ *    dense (npix, C) rows; v = fp16(a + b) is kept for the backward; y / dy are slices with row strides ldy / lddy.  Backward:
+ *    g = dy * SiLU'(v), the gradient of BOTH branches (one buffer).
+ *  adown: ADown's pooling front (upstream ADown.forward): t = avg_pool2d(x, 2, 1, 0); p1 = t[:, :c] (B,H-1,W-1,c);
+ *    p2 = max_pool2d(t[:, c:], 3, 2, 1) (B,Ho,Wo,c), Ho = (H-2)/2+1; argmax (B,Ho,Wo,c) uint8 = window position 3*ky+kx of the first
+ *    maximum in row-major order (torch's rule), written by the forward and read by the backward, which GATHERS: gx (B,H,W,2c) from the
+ *    gradients g1 of p1 and g2 of p2 in a fixed order (no atomics); accumulate = 1 adds fp16(result) to what gx holds. */
+int m355_addsilu_fwd_launch(const void* a, const void* b, void* v, void* y, int64_t npix, int32_t ldy, int32_t C, void* stream);
+int m355_addsilu_bwd_launch(const void* v, const void* dy, int32_t lddy, void* g, int64_t npix, int32_t C, void* stream);
+int m355_adown_fwd_launch(const void* x, int64_t x_bstride, int32_t ldx, void* p1, int64_t p1_bstride, int32_t ld1, void* p2,
+                          int64_t p2_bstride, int32_t ld2, uint8_t* argmax, int32_t B, int32_t H, int32_t W, int32_t c, void* stream);
+int m355_adown_bwd_launch(const void* g1, int64_t g1_bstride, int32_t ld1, const void* g2, int64_t g2_bstride, int32_t ld2,
+                          const uint8_t* argmax, void* gx, int64_t gx_bstride, int32_t ldg, int32_t B, int32_t H, int32_t W, int32_t c,
+                          int32_t accumulate, void* stream);
 int m355_upsample2x_launch(const void* x, int64_t x_bstride, int32_t ldx, void* y, int64_t y_bstride, int32_t ldy,
                            int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
 /* Gradient glue of the training step (each replaces a strided torch expression reached from yolo_seg_train.py:12's backward):

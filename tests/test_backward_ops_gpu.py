@@ -262,3 +262,71 @@ def test_input_conversion_equals_float_div_255_half(npx, cuda_device):
         want = torch.zeros((npx, 8), dtype=torch.float16)
         want[:, :3] = torch.from_numpy((src[shift:].view(npx, 3).numpy().astype(np.float32) / np.float32(255.0)).astype(np.float16))
         assert torch.equal(out.cpu(), want)
+
+
+@pytest.mark.parametrize("B,H,W,c,acc", [(2, 16, 16, 16, False), (1, 20, 28, 64, True), (3, 10, 10, 8, False), (2, 40, 40, 128, True)])
+def test_adown_pooling_front_forward_and_backward_match_torch(B, H, W, c, acc, cuda_device):
+    """ADown's pooling front (upstream ADown.forward: avg_pool2d(x, 2, 1, 0), chunk, max_pool2d(., 3, 2, 1)) as the two HIP launches of
+    the v9c training graph, against torch on fp32 copies of the same fp16 input -- values, the stored argmax (through the backward:
+    tie-heavy inputs, quantised to a few levels) and the gathered input gradient; store and accumulate forms."""
+    from defectdetection_viaobjectdetection_amd import _capi
+    g = torch.Generator().manual_seed(B * 1000 + H * W + c)
+    x = (torch.randint(-3, 4, (B, 2 * c, H, W), generator=g).float() / 2).half()      # few distinct values: many equal maxima per window
+    xf = x.float().requires_grad_(True)
+    t = F.avg_pool2d(xf, 2, 1, 0)
+    p1, p2 = t[:, :c], F.max_pool2d(t[:, c:], 3, 2, 1)
+    g1 = torch.randn(p1.shape, generator=g).half().float()
+    g2 = torch.randn(p2.shape, generator=g).half().float()
+    (gx,) = torch.autograd.grad((p1, p2), xf, (g1, g2))
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d_x = nhwc16(x.float(), cuda_device)
+    Ho, Wo = H // 2, W // 2
+    d_p1 = torch.empty((B, H - 1, W - 1, c), dtype=torch.float16, device=cuda_device)
+    d_p2 = torch.empty((B, Ho, Wo, c), dtype=torch.float16, device=cuda_device)
+    d_arg = torch.empty((B, Ho, Wo, c), dtype=torch.uint8, device=cuda_device)
+    _capi.check(_capi.lib.m355_adown_fwd_launch(_p(d_x), H * W * 2 * c, 2 * c, _p(d_p1), (H - 1) * (W - 1) * c, c, _p(d_p2), Ho * Wo * c, c,
+                                                _p(d_arg), B, H, W, c, st))
+    assert torch.equal(d_p1.cpu(), p1.detach().permute(0, 2, 3, 1).half())
+    assert torch.equal(d_p2.cpu(), p2.detach().permute(0, 2, 3, 1).half())
+    old = torch.randn(B, H, W, 2 * c, generator=g).half()
+    d_gx = old.to(cuda_device).clone() if acc else torch.full((B, H, W, 2 * c), float("nan"), dtype=torch.float16, device=cuda_device)
+    d_g1, d_g2 = nhwc16(g1, cuda_device), nhwc16(g2, cuda_device)        # (named: a temporary inside the argument list is freed at once)
+    _capi.check(_capi.lib.m355_adown_bwd_launch(_p(d_g1), (H - 1) * (W - 1) * c, c, _p(d_g2), Ho * Wo * c, c,
+                                                _p(d_arg), _p(d_gx), H * W * 2 * c, 2 * c, B, H, W, c, 1 if acc else 0, st))
+    want = gx.permute(0, 2, 3, 1).half()
+    if acc:
+        want = (old.float() + want.float()).half()
+    got = d_gx.cpu()
+    assert torch.isfinite(got).all()
+    # sums of <= 16 fp32 terms in a different order, then one fp16 rounding: equal up to an ulp on a handful of elements
+    assert rel_l2(got.float(), want.float()) <= 2e-4
+    assert float((got.float() - want.float()).abs().max()) <= 4e-3 * float(want.float().abs().max())
+
+
+@pytest.mark.parametrize("npix,Cc,ldy", [(1000, 64, 64), (777, 128, 320), (64 * 400, 256, 256)])
+def test_repconv_tail_silu_of_the_branch_sum_matches_torch(npix, Cc, ldy, cuda_device):
+    """RepConvN's tail y = SiLU(a + b) and its backward g = dy * SiLU'(a + b) (one gradient for both branches), against the torch
+    expressions the v9c training graph used before (fp16 sum kept, fp32 SiLU, one rounding)."""
+    from defectdetection_viaobjectdetection_amd import _capi
+    g = torch.Generator().manual_seed(npix + Cc)
+    a = (torch.randn(npix, Cc, generator=g) * 2).half().to(cuda_device)
+    b = (torch.randn(npix, Cc, generator=g) * 2).half().to(cuda_device)
+    dy_full = torch.randn(npix, ldy, generator=g).half().to(cuda_device)
+    y_full = torch.zeros(npix, ldy, dtype=torch.float16, device=cuda_device)
+    v = torch.empty(npix, Cc, dtype=torch.float16, device=cuda_device)
+    gg = torch.empty(npix, Cc, dtype=torch.float16, device=cuda_device)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    off = ldy - Cc
+    _capi.check(_capi.lib.m355_addsilu_fwd_launch(_p(a), _p(b), _p(v), C.c_void_p(y_full.data_ptr() + 2 * off), npix, ldy, Cc, st))
+    _capi.check(_capi.lib.m355_addsilu_bwd_launch(_p(v), C.c_void_p(dy_full.data_ptr() + 2 * off), ldy, _p(gg), npix, Cc, st))
+    torch.cuda.synchronize()
+    v_ref = torch.add(a, b)
+    assert torch.equal(v, v_ref)
+    vf = v_ref.float()
+    y_ref = F.silu(vf)
+    sig = torch.sigmoid(vf)
+    g_ref = dy_full[:, off:].float() * (sig * (1.0 + vf * (1.0 - sig)))
+    assert float((y_full[:, :off]).abs().max()) == 0.0 if off else True
+    # v_exp / v_rcp sigmoid (1 ulp in fp32) then one fp16 rounding: at most one fp16 ulp apart
+    assert rel_l2(y_full[:, off:].float().cpu(), y_ref.cpu()) <= 3e-4
+    assert rel_l2(gg.float().cpu(), g_ref.cpu()) <= 3e-4
