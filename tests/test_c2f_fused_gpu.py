@@ -162,3 +162,34 @@ def test_weights_in_registers_kernels_equal_the_im2col_forms(cuda_device, size, 
               f"max {float(dp[..., :4].max()):.3f}; protos rel-L2 {rel:.2e}")
         assert q(dp[..., 4], .99) <= 1e-3 and q(dp[..., :4], .99) <= 0.15 and q(dp[..., :4], .999) <= 0.45
         assert float(dp[..., 4].max()) <= 5e-3 and float(dp[..., :4].max()) <= 1.3 and rel <= 2e-3
+
+
+@pytest.mark.parametrize("size,batch", [((480, 480), 1), ((480, 480), 3), ((320, 480), 1)])
+def test_upsample_read_through_in_the_register_kernel_with_a_partial_last_tile(cuda_device, size, batch):
+    """model.15.cv1 (Upsample + Concat + 1x1) on conv1x1_wreg's split form against the im2col kernel's read-through, at pixel counts
+    that are not multiples of the 64-pixel tile (60 x 60 = 3 600, 40 x 60 = 2 400): the masked last tile and the tile walk of a short
+    launch.  Same operands, same rounding points: fp32 summation order only."""
+    from defectdetection_viaobjectdetection_amd.engine import SegEngine
+    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
+    from defectdetection_viaobjectdetection_amd.synthetic import synthetic_bscans
+    sd = synthetic_state_dict("s", 1, seed=0)
+    imgs = torch.from_numpy(synthetic_bscans(batch, size[0], size[1], seed=9)).to(cuda_device)
+    outs, kern = {}, {}
+    for name, env in (("split", {}), ("im2col", {"M355_NO_W1_SPLIT": "1"})):
+        os.environ.update(env)
+        try:
+            eng = SegEngine("s", 1, size, max_batch=batch)
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+        eng.load_state_dict(sd)
+        kern[name] = {o["layer"]: o["kernel"] for o in eng.op_infos()}
+        preds, protos = eng.forward(imgs)
+        torch.cuda.synchronize()
+        outs[name] = (preds.clone(), protos.float().clone())
+        eng.close()
+    assert kern["split"]["model.15.cv1"].startswith("conv1x1_wreg<K384,128ch>") and kern["im2col"]["model.15.cv1"].startswith("conv_igemm")
+    dp = (outs["split"][0] - outs["im2col"][0]).abs()
+    rel = float((outs["split"][1] - outs["im2col"][1]).norm() / outs["im2col"][1].norm())
+    assert torch.isfinite(outs["split"][0]).all()
+    assert float(dp[..., 4].max()) <= 2e-3 and float(dp[..., :4].max()) <= 0.5 and rel <= 1e-3
