@@ -250,7 +250,11 @@ struct Builder {
     const int c = out.c / 2;
     const int cat = tensor(H, W, (2 + n) * c);
     conv(name + ".cv1", in, Slice{cat, 0, 2 * c}, 1, 1, Slice(), up_src);
-    if (c == 32 && n == 1 && H % 8 == 0 && W % 16 == 0 && out.c == 64 && !getenv("M355_NO_C2F32")) {
+    // (the launch has no run-time fallback -- t and y2 have no tensors -- so the kernel's 31-bit offset bounds (c2f_c32_ok) are
+    // checked here for the largest batch the engine takes: s scale at 640 x 640 from 437 images on keeps the three-launch form)
+    const long c2f_px = (long)e->desc.max_batch * H * W;
+    const bool c2f_addr_ok = c2f_px * (2 + n) * c * 2 < (1L << 31) && c2f_px * e->tensors[out.t].C < (1L << 31);
+    if (c == 32 && n == 1 && H % 8 == 0 && W % 16 == 0 && out.c == 64 && c2f_addr_ok && !getenv("M355_NO_C2F32")) {
       // the whole block body in one launch (c2f_c32.hip): t and y2 never reach HBM, no tensor for either
       const int la = logical(name + ".m.0.cv1", c, c, 3, 1, 1, 0, 1), lb = logical(name + ".m.0.cv2", c, c, 3, 1, 1, 0, 1);
       const int lc = logical(name + ".cv2", 3 * c, out.c, 1, 1, 1, 0, 1);
