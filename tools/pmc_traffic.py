@@ -28,7 +28,7 @@ MANGLED = {"ILi4ELi4ELi2ELi2EEEvNS_8ConvArgsEiiii": "conv3x3_halo<128ch>", "ILi4
 def label(name):
     # conv_igemm_kernel<MT, NT, WCH, WPX, KS, EPI>: the epilogue selector (0 plain, 1 decode, 2 phase + 1x1) is not part of the label
     name = re.sub(r"(conv_igemm_kernel<\d+, \d+, \d+, \d+, \d+), \d+>", r"\1>", name)
-    mw = re.search(r"conv1x1_wreg_kernel<(\d+), (\d+)>", name)
+    mw = re.search(r"conv1x1_wreg_kernel<(\d+), (\d+)", name)      # <K, CB, PB, SPLIT> since round 4 (<K, CB> before)
     if mw:
         return f"conv1x1_wreg<K{mw.group(1)},{int(mw.group(2)) * 32}ch>"
     for k, v in LABELS.items():
