@@ -355,13 +355,14 @@ __global__ __launch_bounds__(64 * C::NW, C::NW / 4) void planes_kernel(const Pla
   const char* wbase_b_next = (const char*)a.wfb + (nxt.ch / 32 + wc) * wblock;        // ... the block's next tile
 
   // ---- prologue: input plane 0 into slot 0, the weight fragments of the first phase
+  // (the fragments first: their latency -- a cold L2 for the first blocks of a launch -- covers the piece address arithmetic)
+  load_frags(C::PAIR ? wbase_a : wbase_b, st.A);
   piece_offsets(cur);
 #pragma unroll
   for (int m = 0; m < C::PIT; ++m) {
     const int k = wave + C::NW * m;
     if (k < g.npieces) dma16(st.rs_x, st.pvoff[m], cur.b * img_stride, smem + g.off_x + k * 1024);
   }
-  load_frags(C::PAIR ? wbase_a : wbase_b, st.A);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (a.stamps) stamp[1] = __builtin_amdgcn_s_memtime();
