@@ -222,6 +222,155 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* ws, floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of the STEM (3x3 / s2 / p1 on the 8-channel padded input rows, Cout <= 64; upstream model.0 reached from
+// yolo_seg_train.py:12's backward).  It is the LAST kernel of a training step -- dZ of layer 0 exists only when everything else is
+// done -- so nothing overlaps it, and the pixel-axis GEMM above gives it a 128 x 128 tile for a 32 x 72 result: 485 us at batch 64
+// @640 for 840 MB of operands (1.7 TB/s), the exposed tail of the step.
+// Here a WAVE owns a stream of chunks (64 consecutive output pixels of one row): dZ [64 px][Cout] and the three input rows
+// [3][129 px][8 ch] go to a wave-private LDS image through registers (the next chunk's loads are in flight while this one is
+// multiplied), the fragments are gathered with 2-byte LDS reads (the matrices are tiny: 12 MFMAs per chunk), accumulators live in
+// registers for the whole stream.  D[co][n], n = (tap, ci) = the KRSC column.  The four waves of a block add their tiles in wave
+// order and the block writes ONE partial slab; wgrad_reduce_kernel adds the slabs in block order: bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------
+typedef float float16v __attribute__((ext_vector_type(16)));
+constexpr int SW_PX = 64;                  // output pixels per chunk
+constexpr int SW_XCOLS = 2 * SW_PX + 1;    // input columns a chunk touches (2 wo0 - 1 .. 2 wo0 + 127)
+constexpr int SW_XPITCH = SW_XCOLS + 1;    // LDS pitch of an input row in pixels (16 bytes each)
+
+template <int MB>
+__global__ __launch_bounds__(256) void wgrad_stem_kernel(const half_t* dz, long dz_bs, int lddz, const half_t* x, long x_bs, int B, int Ho,
+                                                         int Wo, int Cout, float* out, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ZROW = MB * 64;                                   // bytes per pixel row of the dZ image (MB * 32 channels)
+  constexpr int WBYTES = SW_PX * ZROW + 3 * SW_XPITCH * 16;       // one wave's images
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kg = lane >> 5;
+  char* const zb = smem + wave * WBYTES;
+  char* const xb = zb + SW_PX * ZROW;
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  const int segs = Wo / SW_PX;
+  const long total = (long)B * Ho * segs;
+  const long nwv = (long)gridDim.x * 4;
+  const int cpp = Cout / 8;                                       // 16-byte chunks per dZ pixel
+  constexpr int ZL = MB * 4;                                      // dZ loads per lane and chunk at the full width
+  // channels Cout .. MB * 32 of the dZ image stay zero (Cout = 16, 48): cleared once
+  for (int i = lane; i < SW_PX * ZROW / 16; i += 64) *(half8*)(zb + i * 16) = half8{0, 0, 0, 0, 0, 0, 0, 0};
+
+  half8 zr[ZL], xr[9];
+  auto fetch = [&](long c) __attribute__((always_inline)) {
+    const int seg = (int)(c % segs);
+    const long r = c / segs;
+    const int ho = (int)(r % Ho);
+    const long b = r / Ho;
+    const int wo0 = seg * SW_PX;
+    const half_t* zrow = dz + b * dz_bs + ((long)ho * Wo + wo0) * lddz;
+#pragma unroll
+    for (int i = 0; i < ZL; ++i) {
+      const int q = i * 64 + lane;
+      const int px = q / cpp, cc = q - px * cpp;
+      zr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (px < SW_PX) zr[i] = *(const half8*)(zrow + (long)px * lddz + cc * 8);
+    }
+    const half_t* xim = x + b * x_bs;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int iy = 2 * ho - 1 + kh;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int t = j * 64 + lane, ix = 2 * wo0 - 1 + t;
+        xr[kh * 3 + j] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+        if (t < SW_XCOLS && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) xr[kh * 3 + j] = *(const half8*)(xim + ((long)iy * Wi + ix) * 8);
+      }
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < ZL; ++i) {
+      const int q = i * 64 + lane;
+      const int px = q / cpp, cc = q - px * cpp;
+      if (px < SW_PX) *(half8*)(zb + px * ZROW + cc * 16) = zr[i];
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int t = j * 64 + lane;
+        if (t < SW_XCOLS) *(half8*)(xb + (kh * SW_XPITCH + t) * 16) = xr[kh * 3 + j];
+      }
+  };
+
+  float16v acc[MB][3];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mb][g][i] = 0.f;
+  // B fragment columns of this lane: n = 32 g + l31 -> tap = n / 8 (valid < 9), channel n % 8
+  int boff[3];
+  bool bval[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const int n = 32 * g + l31, tap = n >> 3, ci = n & 7;
+    bval[g] = tap < 9;
+    const int kh = bval[g] ? tap / 3 : 0, kw = bval[g] ? tap - 3 * kh : 0;
+    boff[g] = ((kh * SW_XPITCH + kw) * 8 + ci) * 2;                // + 32 bytes per output pixel (two input columns)
+  }
+
+  long c = (long)blockIdx.x * 4 + wave;
+  if (c < total) fetch(c);
+  for (; c < total; c += nwv) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (this wave's reads of the previous chunk's images are done)
+    stash();
+    if (c + nwv < total) fetch(c + nwv);
+#pragma unroll
+    for (int ks = 0; ks < SW_PX / 16; ++ks) {
+      const int p0 = 16 * ks + 8 * kg;                             // this lane's eight pixels (the K values of its fragments)
+      half8 af[MB], bf[3];
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) af[mb][j] = *(const half_t*)(zb + (p0 + j) * ZROW + (mb * 32 + l31) * 2);
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf[g][j] = bval[g] ? *(const half_t*)(xb + boff[g] + (p0 + j) * 32) : (half_t)0.f;
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[mb][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mb], bf[g], acc[mb][g], 0, 0, 0);
+    }
+  }
+  // ---- the block's tile = its four waves' tiles added in wave order (through LDS, reusing the image memory)
+  __syncthreads();
+  float* const red = (float*)smem;                                 // [wave][MB * 32][96]
+  constexpr int TILE = MB * 32 * 96;
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = mb * 32 + 8 * (i >> 2) + 4 * kg + (i & 3);
+        red[wave * TILE + row * 96 + 32 * g + l31] = acc[mb][g][i];
+      }
+  __syncthreads();
+  float* const slab = out + (nsplit > 1 ? (long)blockIdx.x * Cout * 72 : 0);
+  for (int e = tid; e < Cout * 72; e += 256) {
+    const int co = e / 72, n = e - co * 72;
+    const float* r = red + co * 96 + n;
+    slab[e] = ((r[0] + r[TILE]) + r[2 * TILE]) + r[3 * TILE];
+  }
+}
+
+bool wgrad_stem_ok(int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, int lddz, int ldx, long x_bstride) {
+  static const bool off = getenv("M355_NO_WGRAD_STEM") != nullptr;
+  return !off && ksize == 3 && stride == 2 && pad == 1 && Cin == 8 && ldx == 8 && x_bstride == (long)Hi * Wi * 8 && Cout >= 8 && Cout <= 64 &&
+         Cout % 8 == 0 && lddz >= Cout && Hi == 2 * Ho && Wi == 2 * Wo && Wo % SW_PX == 0;
+}
+
 void wgrad_plan(int M, int Cout, int N, int* splitk, int* steps_per_split) {
   const int tiles = ((Cout + 127) / 128) * ((N + 127) / 128);
   const int steps_total = (M + KST - 1) / KST;
@@ -259,6 +408,30 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
     if (rc != 0) return rc;
     if (sk > 1) {
       const long n = (long)Cout * 9 * Cin;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, sk);
+    }
+    return (int)hipGetLastError();
+  }
+  if (wgrad_stem_ok(Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad, lddz, ldx, x_bstride)) {
+    // the stem: one partial slab per block, as many blocks as the pixel-axis GEMM would use splits (the caller's workspace is sized for those)
+    int sk = 1, sps = 1;
+    wgrad_plan(B * Ho * Wo, Cout, 72, &sk, &sps);
+    const long chunks = (long)B * Ho * (Wo / SW_PX);
+    if ((long)sk * 4 > chunks) sk = (int)((chunks + 3) / 4);
+    if (sk < 1) sk = 1;
+    if (sk > 1 && (!ws || ws_bytes < (size_t)sk * Cout * 72 * sizeof(float))) return -3;
+    const int mb = Cout > 32 ? 2 : 1;
+    const int wbytes = SW_PX * mb * 64 + 3 * SW_XPITCH * 16;
+    int lds = 4 * wbytes;
+    if (lds < 4 * mb * 32 * 96 * 4) lds = 4 * mb * 32 * 96 * 4;
+    auto k = mb == 2 ? wgrad_stem_kernel<2> : wgrad_stem_kernel<1>;
+    if (lds > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(sk), dim3(256), lds, s, dz, dz_bstride, lddz, x, x_bstride, B, Ho, Wo, Cout, sk > 1 ? ws : dw, sk);
+    if (sk > 1) {
+      const long n = (long)Cout * 72;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, sk);
     }
     return (int)hipGetLastError();

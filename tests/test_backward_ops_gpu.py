@@ -134,6 +134,13 @@ WGRAD_CASES = [
     (1, 16, 32, 128, 32, 3, 1),       # 1 x 2
     (1, 19, 35, 32, 64, 3, 1),        # 2 x 1, ragged rows and columns
     (2, 16, 48, 48, 96, 3, 1),        # m-scale widths: half-empty channel tiles on both sides
+    # the stem (3x3 / s2 on the 8-channel padded input rows, Cout <= 64, output rows in 64-pixel chunks): wgrad_stem_kernel
+    (2, 128, 128, 8, 32, 3, 2),       # s scale: one 32-channel block, first / last rows and columns zero-padded
+    (1, 64, 256, 8, 48, 3, 2),        # m scale: two channel blocks, the second half empty
+    (3, 32, 128, 8, 16, 3, 2),        # n scale
+    (5, 16, 384, 8, 64, 3, 2),        # two full channel blocks
+    (4, 320, 512, 8, 32, 3, 2),       # 2 560 chunks on 1 536 waves: the register prefetch of a wave's next chunk, 384 partial slabs
+    (2, 64, 96, 8, 32, 3, 2),         # 48 output columns: not in 64-pixel chunks -> the pixel-axis GEMM
     (3, 8, 32, 16, 24, 3, 1),         # n-scale widths
 ]
 
