@@ -91,7 +91,14 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     const int orig = blockIdx.x, xcd = orig & 7, q = nwg >> 3, r = nwg & 7;
     lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
   }
-  const int nk = a.Kpad / BK;
+  // K steps of a tile.  phase == 3 (stride-2 dgrad, a channel tile inside one phase, one tile per block): a phase's weight rows hold
+  // only the taps it has -- (1 + a)(1 + b) of the four window slots, compact -- and its K loop ends there: 9 tap slots over the four
+  // phases instead of 16.
+  int nk = a.Kpad / BK;
+  if (KS == 2 && a.phase == 3) {
+    const int q = ((lb % tiles_ch) * BCH) / a.convt_co;
+    nk = (1 + (q >> 1)) * (1 + (q & 1)) * a.Cin / BK;
+  }
   const int my_tiles = lb < total ? (total - lb + nwg - 1) / nwg : 0;
   if (my_tiles == 0) return;
   const int total_stages = my_tiles * nk;
@@ -116,6 +123,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
   const half_t* wsrc[W_IT]; // this lane's weight rows (+ chunk column)
   int ld_tile = lb;         // loader cursor: tile, K step within the tile, global stage count
   int ld_t = 0, ld_g = 0;
+  int ld_qb = 0;            // phase == 3: column parity b of the loader tile's phase (taps per window row = 1 + b)
 
   auto loader_setup = [&](int tile) __attribute__((always_inline)) {
     int tile_px, tile_ch;
@@ -145,8 +153,9 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
       int pad_y = a.pad, pad_x = a.pad;
       if (KS == 2 && a.phase) {   // phase conv: the 2x2 window of phase (py, px) starts at (h - 1 + py, w - 1 + px)
         const int q = ch_base / a.convt_co;
-        pad_y = a.phase == 2 ? 0 : 1 - (q >> 1);   // (phase == 2, the stride-2 dgrad: every phase's window starts at (h, w))
-        pad_x = a.phase == 2 ? 0 : 1 - (q & 1);
+        pad_y = a.phase >= 2 ? 0 : 1 - (q >> 1);   // (phase >= 2, the stride-2 dgrad: every phase's window starts at (h, w))
+        pad_x = a.phase >= 2 ? 0 : 1 - (q & 1);
+        ld_qb = q & 1;
       }
       const int hi0 = ho * a.stride - pad_y;
       const int wi0 = wo * a.stride - pad_x;
@@ -219,8 +228,13 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     } else {
       tap = (int)(((float)kq + 0.5f) * inv_cin);
       cin = kq - tap * a.Cin;
-      const int kh = (KS == 3) ? ((tap * 11) >> 5) : (tap >> 1);  // tap / KS for the few taps that exist
-      const int kw = tap - kh * KS;
+      int kh = (KS == 3) ? ((tap * 11) >> 5) : (tap >> 1);  // tap / KS for the few taps that exist
+      int kw = tap - kh * KS;
+      if (KS == 2 && a.phase == 3) {   // compact taps of the phase: 1 + b per window row
+        kh = ld_qb ? (tap >> 1) : tap;
+        kw = ld_qb ? (tap & 1) : 0;
+        tap = 2 * kh + kw;             // the bit of the window slot in rowmask
+      }
       tapoff = a.tmode ? (cin - ((kh >> 1) * a.Wi + (kw >> 1)) * a.ldx) : ((kh * a.Wi + kw) * a.ldx + cin);
     }
     char* ab = sb + BCH * ROWB;
@@ -622,7 +636,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
     // phase conv: pixel-shuffle store, bias by border class of the output pixel.  The stride-2 dgrad form (phase == 2) comes here
     // only to accumulate into a gradient slice that already holds a consumer's contribution (a.res); without one it takes the
     // ConvTranspose fast stores below, and with several phases per channel tile (convt_co < tile) the generic epilogue.
-    if (KS == 2 && MT >= 2 && a.phase && !(a.phase == 2 && (fast_t || a.convt_co % BCH))) {
+    if (KS == 2 && MT >= 2 && a.phase && !(a.phase >= 2 && (fast_t || a.convt_co % BCH))) {
       const int q = ch_base / a.convt_co, dy = q >> 1, dx = q & 1;
       const int co = ch_base - q * a.convt_co + wch * MT * 16 + g * 8;
 #pragma unroll
@@ -634,7 +648,7 @@ __global__ __launch_bounds__(WCH * WPX * 64, (WCH * WPX == 8 ? 4 : 2)) void conv
         fast_divmod(pix, a.Wo, inv_wo, ho, wo);
         const int Y = 2 * ho + dy, X = 2 * wo + dx;
         const int ry = Y == 0 ? 0 : (Y == 2 * a.Ho - 1 ? 2 : 1), rx = X == 0 ? 0 : (X == 2 * a.Wo - 1 ? 2 : 1);
-        const float* bp = a.bias + (a.phase == 2 ? 0 : (ry * 3 + rx) * a.convt_co) + co;
+        const float* bp = a.bias + (a.phase >= 2 ? 0 : (ry * 3 + rx) * a.convt_co) + co;
         half_t* yp = (half_t*)a.y + (long)bb * a.y_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldy + co;
         const half_t* rp = a.res ? a.res + (long)bb * a.r_bstride + ((long)Y * (2 * a.Wo) + X) * a.ldr + co : nullptr;
 #pragma unroll
@@ -928,16 +942,19 @@ bool conv_forced_tile_extent(int tile, int cout, int* bch, int* bpx) {
 int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   ConvArgs a = a0;
   if (knobs().no_fast_epi) a.dbg |= 256;
-  if (knobs().persist & (a.ksize == 1 ? 1 : 2)) a.dbg |= 64;
+  if ((knobs().persist & (a.ksize == 1 ? 1 : 2)) && a.phase != 3) a.dbg |= 64;
   if (a.ksize < 1 || a.ksize > 3) return -1;
   if (a.ksize == 2 && !a.phase && (a.stride != 2 || a.pad != 0 || a.tmode)) return -1;  // the ConvT-dgrad form ...
   if (a.ksize == 2 && a.phase == 1 && (a.stride != 1 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 64)) return -1;  // ... or a phase conv
   // ... or the dgrad of a 3x3 / stride-2 / pad-1 conv as four phase convs (phase == 2): x is dY, Cout = 4 * convt_co virtual channels
   // (phase q = 2 * (row parity) + column parity of the dX pixel, then the forward input channel), 2x2 windows starting at (h, w)
-  if (a.ksize == 2 && a.phase == 2 && (a.stride != 1 || a.pad != 0 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 8 || a.w2 || a.act ||
-                                       a.Cout != 4 * a.convt_co))
+  if (a.ksize == 2 && a.phase >= 2 && (a.stride != 1 || a.pad != 0 || a.tmode || a.out_f32 || a.convt_co <= 0 || a.convt_co % 8 || a.w2 || a.act ||
+                                        a.Cout != 4 * a.convt_co))
     return -1;
-  if (a.phase < 0 || a.phase > 2 || (a.phase && a.ksize != 2)) return -1;
+  // phase == 3: the same with COMPACT weight rows (a phase's K axis holds only its (1 + a)(1 + b) taps, its K loop ends there):
+  // needs the channel tile inside one phase and one tile per block
+  if (a.phase == 3 && (a.convt_co % 64 || a.Cin % BK || (a.dbg & 64))) return -1;
+  if (a.phase < 0 || a.phase > 3 || (a.phase && a.ksize != 2)) return -1;
   if (a.Cin % 8 || a.ldx % 8 || (!a.out_f32 && (a.ldy % 8 || a.Cout % 8))) return -1;
   if (a.M >= (1 << 24)) return -1;  // fast_divmod range
   // the loader keeps row offsets as 32-bit counts of 8 elements: every stride a multiple of 8, the input within 2^34 elements
@@ -951,11 +968,11 @@ int launch_conv_igemm(const ConvArgs& a0, int force_tile, hipStream_t s) {
   if (tile < 0) tile = conv_pick_tile(a.Cout, a.M);
   if (a.ksize == 2 && a.phase == 1 && ((tile == TILE_128x128 && a.convt_co % 128) || (tile != TILE_128x128 && tile != TILE_64x128)))
     return -1;   // a channel tile must lie inside one phase
-  if (a.ksize == 2 && a.phase == 2) {   // a tile inside one phase, or whole phases inside a tile (then no accumulation: generic epilogue)
+  if (a.ksize == 2 && a.phase >= 2) {   // a tile inside one phase, or whole phases inside a tile (then no accumulation: generic epilogue)
     if (force_tile < 0 && tile == TILE_128x128 && a.convt_co % 128 && a.convt_co % 64 == 0) tile = TILE_64x128;
     const int bch = tile == TILE_128x128 ? 128 : 64;
     if (tile != TILE_128x128 && tile != TILE_64x128) return -1;
-    if (a.convt_co % bch && (bch % a.convt_co || a.res)) return -1;
+    if (a.convt_co % bch && (bch % a.convt_co || a.res || a.phase == 3)) return -1;
   }
   if (a.w2 && a.phase && !(a.ksize == 2 && tile == TILE_128x128 && a.convt_co == 128 && a.cout2 == 32 && a.bias2)) return -1;
   if (a.dec_preds && !(a.ksize == 1 && a.out_f32 && tile == TILE_128x128 && a.Cout == 64 + a.dec_nc + a.dec_nm && a.Cout <= 128 &&

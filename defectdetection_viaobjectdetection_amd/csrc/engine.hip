@@ -2219,7 +2219,8 @@ int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const floa
           const half_t v = (half_t)h_w[(((size_t)co * cin + ci) * k + kh) * k + kw];
           if (phases) {
             const int pa = kh == 1 ? 0 : 1, ty = kh == 0 ? 1 : 0, pb = kw == 1 ? 0 : 1, tx = kw == 0 ? 1 : 0;
-            rows[(size_t)((2 * pa + pb) * cin + ci) * Kpad + (size_t)(ty * 2 + tx) * cout + co] = v;
+            const int slot = cin % 64 == 0 ? ty * (1 + pb) + tx : ty * 2 + tx;     // compact taps (phase 3) / window slots (phase 2)
+            rows[(size_t)((2 * pa + pb) * cin + ci) * Kpad + (size_t)slot * cout + co] = v;
           } else {
             const int t = (stride == 1) ? ((k - 1 - kh) * k + (k - 1 - kw)) : (kh * k + kw);
             rows[(size_t)ci * Kpad + (size_t)t * cout + co] = v;
@@ -2241,7 +2242,7 @@ int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const floa
   a.ksize = k; a.stride = 1; a.pad = pad; a.tmode = (stride == 2) ? 1 : 0;
   a.M = B * H * W;
   if (phases) {
-    a.Ho = Ho; a.Wo = Wo; a.Cout = 4 * cin; a.convt_co = cin; a.ksize = 2; a.pad = 0; a.tmode = 0; a.phase = 2;
+    a.Ho = Ho; a.Wo = Wo; a.Cout = 4 * cin; a.convt_co = cin; a.ksize = 2; a.pad = 0; a.tmode = 0; a.phase = cin % 64 == 0 ? 3 : 2;
     a.M = B * Ho * Wo;
   }
   int rc;
@@ -2387,9 +2388,9 @@ int m355_conv_launch(const m355_conv_args* c, void* stream) {
   a.ksize = c->ksize; a.stride = c->stride; a.pad = c->pad; a.M = c->batch * c->ho * c->wo;
   a.act = c->act; a.out_f32 = c->out_f32; a.convt_co = c->convt_co; a.tmode = c->tmode;
   a.zero = (const half_t*)c->zero_page;
-  if (c->tmode == 2) {   // input gradient of a 3x3 / stride-2 / pad-1 conv as four 2x2 phase convs over dY (conv_igemm.hip, phase == 2)
+  if (c->tmode == 2) {   // input gradient of a 3x3 / stride-2 / pad-1 conv as four 2x2 phase convs over dY (conv_igemm.hip, phase 2 / 3)
     a.tmode = 0;
-    a.phase = 2;
+    a.phase = c->convt_co % 64 == 0 ? 3 : 2;   // compact tap layout where a channel tile lies inside one phase
   }
   int rc;
   // 1x1 convs of the training step (forward and input gradients) on conv1x1_wreg.hip where it applies (the weights are gathered

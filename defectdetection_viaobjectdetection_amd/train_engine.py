@@ -382,11 +382,15 @@ class TrainEngine:
                     v = self._pack_view(s.name + ":dgrad4", 4 * cin_p, 4 * cout_p, (4, cin_p, 2, 2, cout_p))
                     wt = w.permute(3, 1, 2, 0)                               # (cin, kh, kw, cout)
                     taps = {0: ((0, 1),), 1: ((0, 2), (1, 0))}              # parity -> ((window slot, forward tap), ...)
+                    # forward input channels in multiples of 64: a phase's taps COMPACT on its K axis (slot ty * (1 + b) + tx), its K loop
+                    # ends behind them (9 tap slots over the four phases instead of 16); otherwise window slots ty * 2 + tx
+                    vf = v.view(4, cin_p, 4, cout_p)
                     for a in (0, 1):
                         for b in (0, 1):
                             for ty, kh in taps[a]:
                                 for tx, kw in taps[b]:
-                                    out.append((v[2 * a + b, :, ty:ty + 1, tx:tx + 1, :s.cout], wt[:, kh:kh + 1, kw:kw + 1, :], ()))
+                                    slot = ty * (1 + b) + tx if cin_p % 64 == 0 else ty * 2 + tx
+                                    out.append((vf[2 * a + b, :, slot:slot + 1, :s.cout].unsqueeze(2), wt[:, kh:kh + 1, kw:kw + 1, :], ()))
         return out
 
     def _repack_torch(self) -> None:

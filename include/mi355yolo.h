@@ -261,7 +261,9 @@ typedef struct {
  * tmode 2: the same gradient as FOUR 2x2 phase convs over dY (one per parity class of the dX pixel): ksize = 2, stride = 1, pad = 0,
  *          hi x wi = ho x wo = the dY map, cout = 4 * convt_co virtual channels (phase-major), convt_co = the forward input channels,
  *          y = the (2 ho) x (2 wo) dX slice, w_packed = [4 * convt_co][(ty, tx, forward cout)] with zero rows for the taps a phase does
- *          not have (16 tap slots for 9 taps; tmode 1 multiplies 36).  Needs convt_co % 64 == 0, or 128 % convt_co == 0 and no res. */
+ *          not have (16 tap slots for 9 taps; tmode 1 multiplies 36).  Needs convt_co % 64 == 0, or 128 % convt_co == 0 and no res.
+ *          With convt_co % 64 == 0 the K axis of a phase is COMPACT -- tap (ty, tx) of phase (a, b) at slot ty * (1 + b) + tx, zeros
+ *          behind -- and the phase's K loop ends after its (1 + a)(1 + b) taps: 9 tap slots in all.  Otherwise slot = ty * 2 + tx. */
 int m355_conv_launch(const m355_conv_args* a, void* stream);
 
 typedef struct {
