@@ -235,6 +235,10 @@ size_t bn_workspace_floats(int C);
 // gradient glue of the training step (train_kernels.hip): fixed-order column sums, nearest-2x upsample backward, input conversion
 long colsum_workspace_floats(long nb, int cols);
 int launch_colsum(const void* src, int src_f16, long nb, long bstride, long rows, int ld, int cols, float* ws, float* out, hipStream_t s);
+// stride-2 input gradient with 32 forward input / 64 output channels as a wave-private chunk stream (conv_dgrad_s2c32.hip; a = the phase-2 form
+// of the im2col kernel: x = dY, y = dX, w = the phase-form packed matrix)
+bool dgrad_s2c32_ok(const ConvArgs& a);
+int launch_dgrad_s2c32(const ConvArgs& a, hipStream_t s);
 // YOLOv9c training glue (train_kernels.hip): RepConvN's SiLU(a + b) and ADown's pooling front, forward and backward
 int launch_addsilu_fwd(const half_t* a, const half_t* b, half_t* v, half_t* y, long npix, int ldy, int C, hipStream_t s);
 int launch_addsilu_bwd(const half_t* v, const half_t* dy, int lddy, half_t* g, long npix, int C, hipStream_t s);

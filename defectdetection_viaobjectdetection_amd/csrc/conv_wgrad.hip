@@ -371,6 +371,153 @@ bool wgrad_stem_ok(int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize,
          Cout % 8 == 0 && lddz >= Cout && Hi == 2 * Ho && Wi == 2 * Wo && Wo % SW_PX == 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient of model.1 of the s scale (3x3 / s2 / p1, 32 -> 64 channels on the 320 x 320 map).  With its input gradient on
+// conv_dgrad_s2c32.hip this launch became the critical path at the end of a training step: the pixel-axis GEMM gives it three
+// 128 x 128 tiles for a 64 x 288 result (half of every tile is channel padding, the input patches are gathered once per tile):
+// 418 us alone, 712 us beside the batch-norm backward of layer 0.
+// Block-cooperative chunk stream: a chunk is 64 consecutive output pixels of one row; the block stages dZ [64 px][64 ch] and the three
+// input rows [3][129 px][32 ch] in LDS through registers (the next chunk's loads are in flight during the multiply).  The 9 taps x 2
+// output-channel blocks = 18 accumulator tiles (32 co x 32 ci each: the KRSC column block of tap t is n = 32 t .. 32 t + 31) are
+// dealt to the four waves 5 / 5 / 4 / 4, so no cross-wave reduction exists: every wave gathers its A fragments (dZ transposed: eight
+// 2-byte LDS reads) and its taps' B fragments and owns its tiles for the whole stream.  One partial slab per block,
+// wgrad_reduce_kernel adds the slabs in block order: bitwise reproducible.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int W2_PX = 64, W2_XCOLS = 2 * W2_PX + 1, W2_XPITCH = W2_XCOLS + 1;
+constexpr int W2_ZBYTES = W2_PX * 128, W2_XBYTES = 3 * W2_XPITCH * 64, W2_LDS = W2_ZBYTES + W2_XBYTES;
+
+// units (tap, channel block) of wave W: taps T0 .. T0 + NT - 1; the first / last tap may hold only one channel block
+template <int W> struct W2Units;
+template <> struct W2Units<0> { static constexpr int T0 = 0, NT = 3; static constexpr int mask[3] = {3, 3, 1}; };
+template <> struct W2Units<1> { static constexpr int T0 = 2, NT = 3; static constexpr int mask[3] = {2, 3, 3}; };
+template <> struct W2Units<2> { static constexpr int T0 = 5, NT = 2; static constexpr int mask[3] = {3, 3, 0}; };
+template <> struct W2Units<3> { static constexpr int T0 = 7, NT = 2; static constexpr int mask[3] = {3, 3, 0}; };
+
+template <int W>
+__device__ __forceinline__ void wgrad_s2c32_run(const half_t* dz, long dz_bs, int lddz, const half_t* x, long x_bs, int ldx, int B, int Ho, int Wo,
+                                                float* slab, char* smem) {
+  using U = W2Units<W>;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int l31 = lane & 31, kg = lane >> 5;
+  char* const zb = smem;
+  char* const xb = smem + W2_ZBYTES;
+  const int Hi = 2 * Ho, Wi = 2 * Wo;
+  const int segs = (Wo + W2_PX - 1) / W2_PX;                   // (the last chunk of a row may be partial: its missing dZ pixels are zeros)
+  const long total = (long)B * Ho * segs;
+  half8 zr[2], xr[7];
+  auto fetch = [&](long c) __attribute__((always_inline)) {
+    const int seg = (int)(c % segs);
+    const long r = c / segs;
+    const int ho = (int)(r % Ho);
+    const long b = r / Ho;
+    const int wo0 = seg * W2_PX;
+    const half_t* zrow = dz + b * dz_bs + ((long)ho * Wo + wo0) * lddz;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = tid + 256 * u;
+      zr[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (wo0 + (q >> 3) < Wo) zr[u] = *(const half8*)(zrow + (long)(q >> 3) * lddz + (q & 7) * 8);
+    }
+    const half_t* xim = x + b * x_bs;
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int q = tid + 256 * u;
+      const int row = q / (W2_XCOLS * 4), rem = q - row * (W2_XCOLS * 4);
+      const int px = rem >> 2, cg = rem & 3;
+      const int iy = 2 * ho - 1 + row, ix = 2 * wo0 - 1 + px;
+      xr[u] = half8{0, 0, 0, 0, 0, 0, 0, 0};
+      if (row < 3 && (unsigned)iy < (unsigned)Hi && (unsigned)ix < (unsigned)Wi) xr[u] = *(const half8*)(xim + ((long)iy * Wi + ix) * ldx + cg * 8);
+    }
+  };
+  auto stash = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int q = tid + 256 * u;
+      *(half8*)(zb + (q >> 3) * 128 + (q & 7) * 16) = zr[u];
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int q = tid + 256 * u;
+      const int row = q / (W2_XCOLS * 4), rem = q - row * (W2_XCOLS * 4);
+      if (row < 3) *(half8*)(xb + ((row * W2_XPITCH + (rem >> 2)) * 32 + (rem & 3) * 8) * 2) = xr[u];
+    }
+  };
+  float16v acc[U::NT][2];
+#pragma unroll
+  for (int t = 0; t < U::NT; ++t)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[t][mb][e] = 0.f;
+  int boff[U::NT];
+#pragma unroll
+  for (int t = 0; t < U::NT; ++t) {
+    const int tap = U::T0 + t, kh = tap / 3, kw = tap - 3 * kh;
+    boff[t] = ((kh * W2_XPITCH + kw) * 32 + l31) * 2;          // + 128 bytes per output pixel (two input columns of 64 bytes)
+  }
+  constexpr int need = U::mask[0] | U::mask[1] | (U::NT > 2 ? U::mask[2] : 0);   // channel blocks this wave multiplies at all
+
+  long c = blockIdx.x;
+  if (c < total) fetch(c);
+  for (; c < total; c += gridDim.x) {
+    __syncthreads();                                           // every wave is done with the previous chunk's images
+    stash();
+    __syncthreads();
+    if (c + gridDim.x < total) fetch(c + gridDim.x);
+#pragma unroll
+    for (int ks = 0; ks < W2_PX / 16; ++ks) {
+      const int p0 = 16 * ks + 8 * kg;
+      half8 af[2], bf[U::NT];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+        if ((need >> mb) & 1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) af[mb][j] = *(const half_t*)(zb + (p0 + j) * 128 + (mb * 32 + l31) * 2);
+        }
+#pragma unroll
+      for (int t = 0; t < U::NT; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf[t][j] = *(const half_t*)(xb + boff[t] + (p0 + j) * 128);
+#pragma unroll
+      for (int t = 0; t < U::NT; ++t)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+          if ((U::mask[t] >> mb) & 1) acc[t][mb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mb], bf[t], acc[t][mb], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < U::NT; ++t)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+      if ((U::mask[t] >> mb) & 1) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = mb * 32 + 8 * (e >> 2) + 4 * kg + (e & 3);
+          slab[co * 288 + (U::T0 + t) * 32 + l31] = acc[t][mb][e];
+        }
+      }
+}
+
+__global__ __launch_bounds__(256) void wgrad_s2c32_kernel(const half_t* dz, long dz_bs, int lddz, const half_t* x, long x_bs, int ldx, int B, int Ho,
+                                                          int Wo, float* out, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  float* const slab = out + (nsplit > 1 ? (long)blockIdx.x * 64 * 288 : 0);
+  switch (wave) {
+    case 0: wgrad_s2c32_run<0>(dz, dz_bs, lddz, x, x_bs, ldx, B, Ho, Wo, slab, smem); break;
+    case 1: wgrad_s2c32_run<1>(dz, dz_bs, lddz, x, x_bs, ldx, B, Ho, Wo, slab, smem); break;
+    case 2: wgrad_s2c32_run<2>(dz, dz_bs, lddz, x, x_bs, ldx, B, Ho, Wo, slab, smem); break;
+    default: wgrad_s2c32_run<3>(dz, dz_bs, lddz, x, x_bs, ldx, B, Ho, Wo, slab, smem); break;
+  }
+}
+
+constexpr int W2_SLABS = 512;   // partial slabs (= blocks) the workspace is sized for
+bool wgrad_s2c32_ok(int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, int lddz, int ldx) {
+  static const bool off = getenv("M355_NO_WGRAD_S2C32") != nullptr;
+  return !off && ksize == 3 && stride == 2 && pad == 1 && Cin == 32 && Cout == 64 && ldx >= 32 && lddz >= 64 && Hi == 2 * Ho && Wi == 2 * Wo &&
+         Wo >= W2_PX;
+}
+
 void wgrad_plan(int M, int Cout, int N, int* splitk, int* steps_per_split) {
   const int tiles = ((Cout + 127) / 128) * ((N + 127) / 128);
   const int steps_total = (M + KST - 1) / KST;
@@ -391,6 +538,10 @@ size_t conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int 
   const int N = ksize * ksize * Cin;
   wgrad_plan(B * Ho * Wo, Cout, N, &sk, &sps);
   size_t need = sk > 1 ? (size_t)sk * Cout * N * sizeof(float) : 0;
+  if (ksize == 3 && Cin == 32 && Cout == 64 && Wo >= W2_PX) {   // (stride unknown here: cover wgrad_s2c32_kernel's slabs)
+    const size_t n2 = (size_t)W2_SLABS * 64 * 288 * sizeof(float);
+    if (n2 > need) need = n2;
+  }
   if (ksize == 3 && conv_wgrad3_ok(B, Ho, Wo, Cin, Cout, 3, 1, 1, 8, 8)) {   // (stride unknown here: cover the stride-1 patch kernel too)
     const size_t n3 = conv_wgrad3_workspace_bytes(B, Ho, Wo, Cin, Cout);
     if (n3 > need) need = n3;
@@ -409,6 +560,27 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
     if (sk > 1) {
       const long n = (long)Cout * 9 * Cin;
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, sk);
+    }
+    return (int)hipGetLastError();
+  }
+  if (wgrad_s2c32_ok(Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad, lddz, ldx) && ws && ws_bytes >= (size_t)64 * 64 * 288 * sizeof(float)) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -2;
+    }
+    const long chunks = (long)B * Ho * ((Wo + W2_PX - 1) / W2_PX);
+    static const int per_cu_x2 = getenv("M355_W2_BLOCKS_X2") ? atoi(getenv("M355_W2_BLOCKS_X2")) : 4;   // blocks per CU x 2 (tuning)
+    long nb = (long)per_cu_x2 * cus / 2;                     // two blocks per CU (registers), one slab each
+    if (nb > W2_SLABS) nb = W2_SLABS;
+    if (nb > chunks) nb = chunks;
+    const long fit = (long)(ws_bytes / ((size_t)64 * 288 * sizeof(float)));
+    if (nb > fit) nb = fit;
+    hipLaunchKernelGGL(wgrad_s2c32_kernel, dim3((unsigned)nb), dim3(256), W2_LDS, s, dz, dz_bstride, lddz, x, x_bstride, ldx, B, Ho, Wo,
+                       nb > 1 ? ws : dw, (int)nb);
+    if (nb > 1) {
+      const long n = 64L * 288;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, (int)nb);
     }
     return (int)hipGetLastError();
   }

@@ -2246,7 +2246,9 @@ int m355_conv2d_dgrad(const void* d_dy, int B, int H, int W, int cin, const floa
     a.M = B * Ho * Wo;
   }
   int rc;
-  if (!a.tmode && !a.phase && conv3x3_halo_ok(a))
+  if (a.phase == 2 && dgrad_s2c32_ok(a))
+    rc = launch_dgrad_s2c32(a, s);
+  else if (!a.tmode && !a.phase && conv3x3_halo_ok(a))
     rc = launch_conv3x3_halo(a, 0, s);
   else
     rc = launch_conv_igemm(a, TILE_AUTO, s);
@@ -2397,7 +2399,9 @@ int m355_conv_launch(const m355_conv_args* c, void* stream) {
   // from the packed rows: the per-step re-pack writes no fragment-ordered copy): 27.4-27.5 -> 27.2-27.3 ms per s-seg b64 step on one box
   static const bool train_w1 = getenv("M355_NO_TRAIN_W1") == nullptr;
   static const bool train_c32 = getenv("M355_NO_TRAIN_C32") == nullptr;   // 32 -> 32 3x3 layers on conv3x3_c32.hip: a further -0.1 ms
-  if (!a.tmode && conv3x3_halo_ok(a))
+  if (a.phase == 2 && dgrad_s2c32_ok(a))
+    rc = launch_dgrad_s2c32(a, (hipStream_t)stream);
+  else if (!a.tmode && conv3x3_halo_ok(a))
     rc = launch_conv3x3_halo(a, 0, (hipStream_t)stream);
   else if (train_w1 && !a.tmode && conv1x1_wreg_ok(a))
     rc = launch_conv1x1_wreg(a, (hipStream_t)stream);

@@ -138,6 +138,7 @@ int m355_postprocess(m355_engine* e, const float* d_preds, const void* d_protos,
  *   M355_NO_PLANES_S2, M355_NO_PLANES_M64   the stride-2 3x3 convs / the 64 -> 64 conv of the 40 x 40 head level off the row-slab kernel
  *   M355_NO_DGRAD_PHASES  (training) stride-2 input gradients as the masked nine-tap gather instead of four phase convs
  *   M355_NO_WGRAD_STEM    (training) layer 0's weight gradient on the pixel-axis GEMM instead of wgrad_stem_kernel
+ *   M355_NO_WGRAD_S2C32, M355_NO_DGRAD_S2C32   (training) model.1's weight / input gradient on the pixel-axis GEMM / the im2col kernel
  *   M355_NO_W1, M355_NO_S2C64, M355_NO_S2C32, M355_NO_PROTOR, M355_NO_PROTOFUSE(3), M355_NO_HEADTAIL, M355_NO_STEMFUSE,
  *   M355_NO_STEM2, M355_NO_CVFUSE, M355_NO_UPFUSE, M355_NO_C32, M355_NO_M32, M355_NO_WIDE, M355_NO_HALO, M355_NO_SLAB,
  *   M355_DECFUSE=1      each falls back from one fused / specialised kernel to the kernels it replaced (names = file names in csrc/)

@@ -29,7 +29,9 @@ DGRAD_CASES = [
     (2, 32, 32, 64, 128, 3, 2),      # stride 2 on even maps: four phase convs over dY, pixel-shuffle fast stores (Wo % 16 == 0)
     (1, 34, 22, 32, 64, 3, 2),       # the same with four phases per channel tile (cin 32) and odd dY sizes (17 x 11): generic epilogue
     (3, 40, 40, 128, 256, 3, 2),
-    (2, 64, 64, 32, 64, 3, 2),       # cin 32, full tiles
+    (2, 64, 64, 32, 64, 3, 2),       # cin 32 / cout 64 with dY rows in 32-pixel chunks: the wave-private chunk stream (conv_dgrad_s2c32.hip)
+    (3, 128, 192, 32, 64, 3, 2),     # ... three chunks per row, last rows / columns of the image (zero neighbours)
+    (9, 320, 320, 32, 64, 3, 2),     # ... more chunks (7 200) than waves in flight (2 048): the register prefetch of a wave's next chunk
     (2, 33, 21, 64, 128, 3, 2),      # odd input sizes: the transposed-stride gather (all nine taps masked per output parity)
     (1, 48, 80, 256, 512, 3, 2),
 ]
@@ -141,6 +143,11 @@ WGRAD_CASES = [
     (5, 16, 384, 8, 64, 3, 2),        # two full channel blocks
     (4, 320, 512, 8, 32, 3, 2),       # 2 560 chunks on 1 536 waves: the register prefetch of a wave's next chunk, 384 partial slabs
     (2, 64, 96, 8, 32, 3, 2),         # 48 output columns: not in 64-pixel chunks -> the pixel-axis GEMM
+    # model.1 of the s scale (3x3 / s2, 32 -> 64): block-cooperative chunk stream, the 18 accumulator tiles dealt to four waves (wgrad_s2c32_kernel)
+    (2, 128, 128, 32, 64, 3, 2),
+    (1, 64, 256, 32, 64, 3, 2),       # two chunks per row; top / bottom / left padding
+    (4, 320, 256, 32, 64, 3, 2),      # 1 280 chunks on 512 blocks: the register prefetch of a block's next chunk, 512 partial slabs
+    (2, 96, 320, 32, 64, 3, 2),       # 160 output columns = 2.5 chunks: the partial last chunk of a row (the s scale at 640 x 640)
     (3, 8, 32, 16, 24, 3, 1),         # n-scale widths
 ]
 
