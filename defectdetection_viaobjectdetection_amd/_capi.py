@@ -138,8 +138,6 @@ SIGNATURES = {
                                         C.c_int32, C.c_int32, _P]),
     "m355_adown_bwd_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, _P]),
-    "m355_wgrad_stem_bn_launch": (C.c_int, [_P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
-                                            C.c_int32, C.c_int32, _P, _P, _P, _P, _P, C.c_int32, _P, _P, C.c_int64, _P]),
     "m355_u8_to_f16x8_launch": (C.c_int, [_P, _P, C.c_int64, _P]),
     "m355_mask_loss_launch": (C.c_int, [_P, _P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P,
                                          C.c_int32, _P, _P]),

@@ -227,11 +227,6 @@ bool conv_wgrad3_ok(int B, int H, int W, int Cin, int Cout, int ksize, int strid
 size_t conv_wgrad3_workspace_bytes(int B, int H, int W, int Cin, int Cout);
 int launch_conv_wgrad3(const half_t* dz, long dz_bs, int lddz, const half_t* x, long x_bs, int ldx, int B, int H, int W, int Cin,
                        int Cout, float* dw, const half_t* zero, float* ws, size_t ws_bytes, int* splitk, hipStream_t s);
-// layer 0: weight gradient with the batch-norm backward's apply pass inside (dy = gradient of the activation, z = pre-norm output)
-int launch_conv_wgrad_stem_bn(const half_t* dy, long dy_bstride, int lddy, const half_t* z, long z_bstride, int ldz, const half_t* x,
-                              long x_bstride, int ldx, int B, int Hi, int Wi, int Ho, int Wo, int Cout, const float* mean, const float* invstd,
-                              const float* gamma, const float* beta, const float* rsum, int act, float* dw, float* ws, size_t ws_bytes,
-                              hipStream_t s);
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
                       int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
                       const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s);

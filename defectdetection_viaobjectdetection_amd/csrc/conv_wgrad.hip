@@ -238,20 +238,9 @@ constexpr int SW_PX = 64;                  // output pixels per chunk
 constexpr int SW_XCOLS = 2 * SW_PX + 1;    // input columns a chunk touches (2 wo0 - 1 .. 2 wo0 + 127)
 constexpr int SW_XPITCH = SW_XCOLS + 1;    // LDS pitch of an input row in pixels (16 bytes each)
 
-// BNF: dz is the gradient of the layer's ACTIVATION (dY of BatchNorm + SiLU) and the batch-norm backward's apply pass
-//   dZ = gamma * invstd * (du - sum(du) / N - xhat * sum(du * xhat) / N),  du = dY * SiLU'(u)
-// (bn_silu_bwd_apply_kernel's arithmetic, operation for operation, rounded to fp16 where that kernel stores) is evaluated while the
-// chunk goes to LDS: layer 0 has no input gradient, so its dZ has no other reader -- 420 MB written and read back at batch 64 @640.
-struct StemBN {
-  const half_t* z; long z_bs; int ldz;
-  const float *mean, *invstd, *gamma, *beta, *rsum;
-  int act; float inv_n;
-};
-__device__ __forceinline__ float wg_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f)); }
-
-template <int MB, bool BNF>
+template <int MB>
 __global__ __launch_bounds__(256) void wgrad_stem_kernel(const half_t* dz, long dz_bs, int lddz, const half_t* x, long x_bs, int B, int Ho,
-                                                         int Wo, int Cout, float* out, int nsplit, const StemBN bn) {
+                                                         int Wo, int Cout, float* out, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ZROW = MB * 64;                                   // bytes per pixel row of the dZ image (MB * 32 channels)
   constexpr int WBYTES = SW_PX * ZROW + 3 * SW_XPITCH * 16;       // one wave's images
@@ -270,19 +259,6 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const half_t* dz, long 
   for (int i = lane; i < SW_PX * ZROW / 16; i += 64) *(half8*)(zb + i * 16) = half8{0, 0, 0, 0, 0, 0, 0, 0};
 
   half8 zr[ZL], xr[9];
-  half8 vr[BNF ? ZL : 1];                                         // BNF: the pre-norm activations Z of the chunk
-  // BNF: per-channel constants of this lane's 8-channel group (64 % cpp == 0: the group is the same for every load of the lane)
-  float bm[8], bis[8], bga[8], bbe[8], bk1[8], bk2[8], bk3[8];
-  if (BNF) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int ch = (lane % cpp) * 8 + j;
-      bm[j] = bn.mean[ch]; bis[j] = bn.invstd[ch]; bga[j] = bn.gamma[ch]; bbe[j] = bn.beta[ch];
-      bk1[j] = bga[j] * bis[j];
-      bk2[j] = bn.rsum[ch] * bn.inv_n;
-      bk3[j] = bn.rsum[Cout + ch] * bn.inv_n;
-    }
-  }
   auto fetch = [&](long c) __attribute__((always_inline)) {
     const int seg = (int)(c % segs);
     const long r = c / segs;
@@ -296,10 +272,6 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const half_t* dz, long 
       const int px = q / cpp, cc = q - px * cpp;
       zr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
       if (px < SW_PX) zr[i] = *(const half8*)(zrow + (long)px * lddz + cc * 8);
-      if (BNF) {
-        vr[i] = half8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (px < SW_PX) vr[i] = *(const half8*)(bn.z + b * bn.z_bs + ((long)ho * Wo + wo0 + px) * bn.ldz + cc * 8);
-      }
     }
     const half_t* xim = x + b * x_bs;
 #pragma unroll
@@ -318,21 +290,7 @@ __global__ __launch_bounds__(256) void wgrad_stem_kernel(const half_t* dz, long 
     for (int i = 0; i < ZL; ++i) {
       const int q = i * 64 + lane;
       const int px = q / cpp, cc = q - px * cpp;
-      half8 o = zr[i];
-      if (BNF) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = ((float)vr[i][j] - bm[j]) * bis[j];
-          float du = (float)zr[i][j];
-          if (bn.act) {
-            const float t = bga[j] * xh + bbe[j];
-            const float sg = wg_sigmoid(t);
-            du *= sg * (1.0f + t * (1.0f - sg));
-          }
-          o[j] = (half_t)(bk1[j] * (du - bk2[j] - xh * bk3[j]));
-        }
-      }
-      if (px < SW_PX) *(half8*)(zb + px * ZROW + cc * 16) = o;
+      if (px < SW_PX) *(half8*)(zb + px * ZROW + cc * 16) = zr[i];
     }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
@@ -591,47 +549,6 @@ size_t conv_wgrad_workspace_bytes(int B, int Ho, int Wo, int Cin, int Cout, int 
   return need;
 }
 
-namespace {
-int launch_wgrad_stem(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int B, int Ho, int Wo, int Cout, float* dw,
-                      float* ws, size_t ws_bytes, const StemBN* bn, hipStream_t s) {
-  // the stem: one partial slab per block, as many blocks as the pixel-axis GEMM would use splits (the caller's workspace is sized for those)
-  int sk = 1, sps = 1;
-  wgrad_plan(B * Ho * Wo, Cout, 72, &sk, &sps);
-  const long chunks = (long)B * Ho * (Wo / SW_PX);
-  if ((long)sk * 4 > chunks) sk = (int)((chunks + 3) / 4);
-  if (sk < 1) sk = 1;
-  if (sk > 1 && (!ws || ws_bytes < (size_t)sk * Cout * 72 * sizeof(float))) return -3;
-  const int mb = Cout > 32 ? 2 : 1;
-  const int wbytes = SW_PX * mb * 64 + 3 * SW_XPITCH * 16;
-  int lds = 4 * wbytes;
-  if (lds < 4 * mb * 32 * 96 * 4) lds = 4 * mb * 32 * 96 * 4;
-  auto k = bn ? (mb == 2 ? wgrad_stem_kernel<2, true> : wgrad_stem_kernel<1, true>) : (mb == 2 ? wgrad_stem_kernel<2, false> : wgrad_stem_kernel<1, false>);
-  if (lds > 65536) {
-    hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return (int)e;
-  }
-  const StemBN none{};
-  hipLaunchKernelGGL(k, dim3(sk), dim3(256), lds, s, dz, dz_bstride, lddz, x, x_bstride, B, Ho, Wo, Cout, sk > 1 ? ws : dw, sk, bn ? *bn : none);
-  if (sk > 1) {
-    const long n = (long)Cout * 72;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, sk);
-  }
-  return (int)hipGetLastError();
-}
-}  // namespace
-
-// The stem's weight gradient with the batch-norm backward's apply pass inside (wgrad_stem_kernel<., true>): dy = gradient of the
-// layer's activation, z = its pre-norm output, rsum = [sum du | sum du * xhat] from the reduction that ran before.
-int launch_conv_wgrad_stem_bn(const half_t* dy, long dy_bstride, int lddy, const half_t* z, long z_bstride, int ldz, const half_t* x,
-                              long x_bstride, int ldx, int B, int Hi, int Wi, int Ho, int Wo, int Cout, const float* mean, const float* invstd,
-                              const float* gamma, const float* beta, const float* rsum, int act, float* dw, float* ws, size_t ws_bytes,
-                              hipStream_t s) {
-  if (!dy || !z || !x || !mean || !invstd || !gamma || !beta || !rsum || !dw) return -1;
-  if (!wgrad_stem_ok(Hi, Wi, 8, Ho, Wo, Cout, 3, 2, 1, lddy, ldx, x_bstride) || ldz % 8 || lddy % 8 || 64 % (Cout / 8)) return -1;
-  StemBN bn{z, z_bstride, ldz, mean, invstd, gamma, beta, rsum, act, 1.0f / (float)((long)B * Ho * Wo)};
-  return launch_wgrad_stem(dy, dy_bstride, lddy, x, x_bstride, B, Ho, Wo, Cout, dw, ws, ws_bytes, &bn, s);
-}
-
 int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t* x, long x_bstride, int ldx, int B,
                       int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, int pad, float* dw,
                       const half_t* zero, float* ws, size_t ws_bytes, hipStream_t s) {
@@ -668,7 +585,28 @@ int launch_conv_wgrad(const half_t* dz, long dz_bstride, int lddz, const half_t*
     return (int)hipGetLastError();
   }
   if (wgrad_stem_ok(Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad, lddz, ldx, x_bstride)) {
-    return launch_wgrad_stem(dz, dz_bstride, lddz, x, x_bstride, B, Ho, Wo, Cout, dw, ws, ws_bytes, nullptr, s);
+    // the stem: one partial slab per block, as many blocks as the pixel-axis GEMM would use splits (the caller's workspace is sized for those)
+    int sk = 1, sps = 1;
+    wgrad_plan(B * Ho * Wo, Cout, 72, &sk, &sps);
+    const long chunks = (long)B * Ho * (Wo / SW_PX);
+    if ((long)sk * 4 > chunks) sk = (int)((chunks + 3) / 4);
+    if (sk < 1) sk = 1;
+    if (sk > 1 && (!ws || ws_bytes < (size_t)sk * Cout * 72 * sizeof(float))) return -3;
+    const int mb = Cout > 32 ? 2 : 1;
+    const int wbytes = SW_PX * mb * 64 + 3 * SW_XPITCH * 16;
+    int lds = 4 * wbytes;
+    if (lds < 4 * mb * 32 * 96 * 4) lds = 4 * mb * 32 * 96 * 4;
+    auto k = mb == 2 ? wgrad_stem_kernel<2> : wgrad_stem_kernel<1>;
+    if (lds > 65536) {
+      hipError_t e = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(k, dim3(sk), dim3(256), lds, s, dz, dz_bstride, lddz, x, x_bstride, B, Ho, Wo, Cout, sk > 1 ? ws : dw, sk);
+    if (sk > 1) {
+      const long n = (long)Cout * 72;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((int)((n + 63) / 64)), dim3(256), 0, s, ws, dw, n, sk);
+    }
+    return (int)hipGetLastError();
   }
   WgradArgs a{};
   a.dz = dz; a.dz_bstride = dz_bstride; a.lddz = lddz; a.x = x; a.x_bstride = x_bstride; a.ldx = ldx;

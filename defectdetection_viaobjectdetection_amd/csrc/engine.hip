@@ -2423,19 +2423,6 @@ int m355_wgrad_launch(const m355_wgrad_args* w, void* stream) {
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "wgrad launch failed: " + std::to_string(rc));
 }
 
-int m355_wgrad_stem_bn_launch(const void* dy, int64_t dy_bstride, int32_t lddy, const void* z, int64_t z_bstride, int32_t ldz, const void* x,
-                              int64_t x_bstride, int32_t ldx, int32_t batch, int32_t hi, int32_t wi, int32_t cout, const float* mean,
-                              const float* invstd, const float* gamma, const float* beta, const float* dbeta_dgamma, int32_t act, float* dw,
-                              float* ws, int64_t ws_bytes, void* stream) {
-  const int rc = launch_conv_wgrad_stem_bn((const half_t*)dy, dy_bstride, lddy, (const half_t*)z, z_bstride, ldz, (const half_t*)x, x_bstride, ldx,
-                                           batch, hi, wi, hi / 2, wi / 2, cout, mean, invstd, gamma, beta, dbeta_dgamma, act, dw, ws,
-                                           (size_t)(ws_bytes < 0 ? 0 : ws_bytes), (hipStream_t)stream);
-  if (rc == -1) return set_err(M355_ERR_INVALID, "stem weight gradient with batch-norm apply: shape not taken (3x3 / s2 on 8-channel rows, even map, "
-                                                 "output rows in 64-pixel chunks, cout in {16, 32, 64})");
-  if (rc == -3) return set_err(M355_ERR_INVALID, "wgrad workspace missing or smaller than m355_wgrad_workspace_bytes()");
-  return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "stem wgrad launch failed: " + std::to_string(rc));
-}
-
 int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C, const float* gamma, const float* beta,
                              float eps, int32_t act, void* y, int32_t ldy, const void* res, int32_t ldr, float* mean,
                              float* invstd, float* ws, float* running_mean, float* running_var, float momentum,
@@ -2450,7 +2437,7 @@ int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C
 int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_t ldz, int32_t lddy, int32_t C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t act,
                              void* dz, int32_t lddz, float* dbeta_dgamma, float* ws, void* stream) {
-  if (!z || !dy || !mean || !invstd || !gamma || !beta || !dbeta_dgamma || !ws) return set_err(M355_ERR_INVALID, "null pointer");   // (dz may be NULL: reductions only)
+  if (!z || !dy || !mean || !invstd || !gamma || !beta || !dz || !dbeta_dgamma || !ws) return set_err(M355_ERR_INVALID, "null pointer");
   const int rc = launch_bn_silu_train_bwd((const half_t*)z, (const half_t*)dy, npix, ldz, lddy, C, mean, invstd, gamma, beta,
                                           dbeta_dgamma, (half_t*)dz, lddz, act, ws, (hipStream_t)stream);
   return rc == 0 ? M355_OK : set_err(M355_ERR_HIP, "bn bwd launch failed: " + std::to_string(rc));

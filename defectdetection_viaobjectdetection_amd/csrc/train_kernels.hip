@@ -421,16 +421,14 @@ int launch_bn_silu_train_fwd(const half_t* z, long npix, int ldz, int C, const f
 int launch_bn_silu_train_bwd(const half_t* z, const half_t* dy, long npix, int ldz, int lddy, int C, const float* mean,
                              const float* invstd, const float* gamma, const float* beta, float* rsum, half_t* dz,
                              int lddz, int act, float* ws, hipStream_t s) {
-  if (C % 8 || ldz % 8 || lddy % 8 || (dz && lddz % 8) || C / 8 > BN_THREADS || !ws) return -1;
+  if (C % 8 || ldz % 8 || lddy % 8 || lddz % 8 || C / 8 > BN_THREADS || !ws) return -1;
   const int lanes_px = BN_THREADS / (C / 8);
   const int gr = grid_red(npix * BN_THREADS / lanes_px / 4);
   hipLaunchKernelGGL(bn_silu_bwd_reduce_kernel, dim3(gr), dim3(BN_THREADS), BN_THREADS * 16 * sizeof(float), s, z, dy, npix, ldz,
                      lddy, C, mean, invstd, gamma, beta, act, ws);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((2 * C + 63) / 64), dim3(FIN_WAVES * 64), 0, s, ws, 2 * C, gr, rsum);
-  // dz == nullptr: the reductions only (dbeta, dgamma); the apply pass runs inside the consumer (layer 0: wgrad_stem_kernel<., true>)
-  if (dz)
-    hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
-                       lddy, C, mean, invstd, gamma, beta, rsum, dz, lddz, act);
+  hipLaunchKernelGGL(bn_silu_bwd_apply_kernel, dim3(grid_px(npix, lanes_px)), dim3(BN_THREADS), 0, s, z, dy, npix, ldz,
+                     lddy, C, mean, invstd, gamma, beta, rsum, dz, lddz, act);
   return (int)hipGetLastError();
 }
 

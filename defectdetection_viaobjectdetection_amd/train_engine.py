@@ -88,7 +88,6 @@ class TrainEngine:
         # input gradients of the stride-2 3x3 convs as four phase convs over dY (16 tap slots for 9 taps) instead of the masked
         # transposed-stride gather (36): M355_NO_DGRAD_PHASES=1 restores the gather (A/B and the parity test)
         self._dgrad_phases = os.environ.get("M355_NO_DGRAD_PHASES") != "1"
-        self._stem_bn_fuse = os.environ.get("M355_NO_STEM_BN_FUSE") != "1"
         # forward: the 1/8-level head + the prototype branch beside the rest of the neck (M355_NO_HEAD_STREAM=1: one stream)
         self._head_stream = None if (os_no_side or os.environ.get("M355_NO_HEAD_STREAM") == "1") else torch.cuda.Stream(device=self.dev)
         self._head_ops = None
@@ -714,20 +713,16 @@ class TrainEngine:
                         self._gview(op["res"]).copy_(self._gview(dst))
                     else:
                         self._gview(op["res"]).add_(self._gview(dst))
-                dyp, dybs, lddy = self._slice_ptr(self.gtensors, dst)
+                dyp, _, lddy = self._slice_ptr(self.gtensors, dst)
+                if "dz" not in sv:
+                    sv["dz"] = torch.empty_like(sv["z"])
                 gb = self.grads[f"{name}.bn.bias"]                        # [dbeta | dgamma] land in the flat buffer
                 assert self.grads[f"{name}.bn.weight"].data_ptr() == gb.data_ptr() + 4 * cout
-                # layer 0 has no input gradient: its dZ has one reader, the weight gradient -- which evaluates the batch-norm apply pass
-                # itself (m355_wgrad_stem_bn_launch), so dZ (420 MB at batch 64 @640) is never written.  M355_NO_STEM_BN_FUSE=1: two launches.
-                fuse0 = (s.cin == 3 and self._stem_bn_fuse and s.k == 3 and s.stride == 2 and cout in (16, 32, 64) and hi == 2 * ho
-                         and wi == 2 * wo and wo % 64 == 0)
-                if not fuse0 and "dz" not in sv:
-                    sv["dz"] = torch.empty_like(sv["z"])
                 check(lib.m355_bn_train_bwd_launch(sv["z"].data_ptr(), dyp, B * ho * wo, cout, lddy, cout,
                                                    sv["mean"].data_ptr(), sv["invstd"].data_ptr(),
                                                    self.params[f"{name}.bn.weight"].data_ptr(),
-                                                   self.params[f"{name}.bn.bias"].data_ptr(), op.get("act", 1),
-                                                   0 if fuse0 else sv["dz"].data_ptr(), cout, gb.data_ptr(), sv["ws"].data_ptr(), st))
+                                                   self.params[f"{name}.bn.bias"].data_ptr(), op.get("act", 1), sv["dz"].data_ptr(), cout,
+                                                   gb.data_ptr(), sv["ws"].data_ptr(), st))
                 ready += [f"{name}.bn.bias", f"{name}.bn.weight", f"{name}.conv.weight"]
                 xp, xbs, ldx = self._slice_ptr(self.tensors, src)
                 gw = self.grads[f"{name}.conv.weight"]
@@ -735,20 +730,8 @@ class TrainEngine:
                     if "dw8" not in sv:
                         sv["dw8"] = torch.empty((cout, 3, 3, 8), device=self.dev)
                     with self._beside(op):      # (every weight gradient on the one side stream: they share the split-K workspace)
-                        if fuse0:
-                            need = int(lib.m355_wgrad_workspace_bytes(B, ho, wo, 8, cout, 3))
-                            if need > self.wgrad_ws.numel() * 4:
-                                torch.cuda.current_stream().synchronize()
-                                self.wgrad_ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=self.dev)
-                            wsb = self.wgrad_ws
-                            check(lib.m355_wgrad_stem_bn_launch(dyp, dybs, lddy, sv["z"].data_ptr(), ho * wo * cout, cout, xp, xbs, ldx, B, hi, wi,
-                                                                cout, sv["mean"].data_ptr(), sv["invstd"].data_ptr(),
-                                                                self.params[f"{name}.bn.weight"].data_ptr(),
-                                                                self.params[f"{name}.bn.bias"].data_ptr(), gb.data_ptr(), op.get("act", 1),
-                                                                sv["dw8"].data_ptr(), wsb.data_ptr(), wsb.numel() * 4, self._stream()))
-                        else:
-                            self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, 8, ho, wo, cout, s.k,
-                                               s.stride, s.k // 2, sv["dw8"])
+                        self._wgrad_launch(sv["dz"].data_ptr(), cout, ho * wo * cout, xp, xbs, ldx, hi, wi, 8, ho, wo, cout, s.k,
+                                           s.stride, s.k // 2, sv["dw8"])
                         gw.copy_(sv["dw8"][..., :3])
                 else:
                     with self._beside(op):

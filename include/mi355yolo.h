@@ -138,7 +138,6 @@ int m355_postprocess(m355_engine* e, const float* d_preds, const void* d_protos,
  *   M355_NO_PLANES_S2, M355_NO_PLANES_M64   the stride-2 3x3 convs / the 64 -> 64 conv of the 40 x 40 head level off the row-slab kernel
  *   M355_NO_DGRAD_PHASES  (training) stride-2 input gradients as the masked nine-tap gather instead of four phase convs
  *   M355_NO_WGRAD_STEM    (training) layer 0's weight gradient on the pixel-axis GEMM instead of wgrad_stem_kernel
- *   M355_NO_STEM_BN_FUSE  (training) layer 0's batch-norm backward apply as its own pass instead of inside the weight-gradient kernel
  *   M355_NO_WGRAD_S2C32, M355_NO_DGRAD_S2C32   (training) model.1's weight / input gradient on the pixel-axis GEMM / the im2col kernel
  *   M355_NO_W1, M355_NO_S2C64, M355_NO_S2C32, M355_NO_PROTOR, M355_NO_PROTOFUSE(3), M355_NO_HEADTAIL, M355_NO_STEMFUSE,
  *   M355_NO_STEM2, M355_NO_CVFUSE, M355_NO_UPFUSE, M355_NO_C32, M355_NO_M32, M355_NO_WIDE, M355_NO_HALO, M355_NO_SLAB,
@@ -281,15 +280,6 @@ typedef struct {
  * slabs in a fixed order.  M355_ERR_INVALID when ws is missing / too small for the shape. */
 size_t m355_wgrad_workspace_bytes(int32_t batch, int32_t ho, int32_t wo, int32_t cin, int32_t cout, int32_t ksize);
 int m355_wgrad_launch(const m355_wgrad_args* a, void* stream);
-/* Layer 0 of the network (3x3 / s2 / p1 on the 8-channel padded input rows, cout in {16, 32, 64}, even map whose output rows split into
- * 64-pixel chunks): weight gradient with the batch-norm backward's APPLY pass evaluated inside -- dy is the gradient of the layer's
- * activation, z its pre-norm output, dbeta_dgamma = [sum du | sum du * xhat] as m355_bn_train_bwd_launch leaves them (call that first with
- * dz = NULL: reductions only).  Layer 0 has no input gradient, so its dZ (420 MB at batch 64 @640) is never written.  dw fp32
- * [cout][3][3][8]; ws / ws_bytes as for m355_wgrad_launch.  Other shapes: M355_ERR_INVALID (use the two separate launches). */
-int m355_wgrad_stem_bn_launch(const void* dy, int64_t dy_bstride, int32_t lddy, const void* z, int64_t z_bstride, int32_t ldz, const void* x,
-                              int64_t x_bstride, int32_t ldx, int32_t batch, int32_t hi, int32_t wi, int32_t cout, const float* mean,
-                              const float* invstd, const float* gamma, const float* beta, const float* dbeta_dgamma, int32_t act, float* dw,
-                              float* ws, int64_t ws_bytes, void* stream);
 
 /* Train-mode BN(+SiLU)(+residual) on slices: y = act(bn(z)) + res.  running_mean / running_var (may be NULL) get the
  * momentum update r = (1 - momentum) * r + momentum * batch_stat (unbiased variance), like torch BatchNorm2d. */
@@ -297,7 +287,6 @@ int m355_bn_train_fwd_launch(const void* z, int64_t npix, int32_t ldz, int32_t C
                              float eps, int32_t act, void* y, int32_t ldy, const void* res, int32_t ldr, float* mean,
                              float* invstd, float* ws, float* running_mean, float* running_var, float momentum,
                              void* stream);
-/* (backward: dz = NULL runs the two reductions only -- dbeta | dgamma -- and leaves the apply pass to the consumer, m355_wgrad_stem_bn_launch) */
 int m355_bn_train_bwd_launch(const void* z, const void* dy, int64_t npix, int32_t ldz, int32_t lddy, int32_t C,
                              const float* mean, const float* invstd, const float* gamma, const float* beta, int32_t act,
                              void* dz, int32_t lddz, float* dbeta_dgamma, float* ws, void* stream);

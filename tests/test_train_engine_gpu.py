@@ -143,30 +143,3 @@ def test_repack_job_kernel_equals_the_torch_copies(cuda_device):
     assert len(got) > 100
     for k, v in eng.packed.items():
         assert torch.equal(got[k], v), k
-
-
-def test_stem_weight_gradient_with_the_bn_apply_inside_equals_the_two_launch_form(cuda_device, monkeypatch):
-    """Layer 0's batch-norm backward apply inside its weight-gradient kernel (m355_wgrad_stem_bn_launch: dZ never written) against the two
-    launches (M355_NO_STEM_BN_FUSE=1): the same operations on the same values in the same order -> every gradient of the network
-    bit for bit, layer 0's included."""
-    from defectdetection_viaobjectdetection_amd.spec import synthetic_state_dict
-    from defectdetection_viaobjectdetection_amd.train_engine import TrainEngine
-    B, size = 2, (256, 256)                       # layer 0 output rows: 128 pixels = two chunks
-    sd = synthetic_state_dict("n", 1, seed=3)
-    g = torch.Generator().manual_seed(7)
-    imgs = torch.randint(0, 256, (B, *size, 3), generator=g, dtype=torch.uint8).to(cuda_device)
-    grads = []
-    for off in (False, True):
-        if off:
-            monkeypatch.setenv("M355_NO_STEM_BN_FUSE", "1")
-        eng = TrainEngine("n", 1, size, B)
-        eng.load_state_dict(sd)
-        raw, protos = eng.forward(imgs)
-        d_raw = torch.sin(torch.arange(raw.numel(), device=cuda_device, dtype=torch.float32)).view_as(raw) * 1e-2
-        d_protos = (torch.cos(torch.arange(protos.numel(), device=cuda_device, dtype=torch.float32)).view_as(protos) * 1e-2).half()
-        eng.backward(d_raw, d_protos)
-        torch.cuda.synchronize()
-        grads.append({k: v.clone() for k, v in eng.grads.items()})
-    assert torch.isfinite(grads[0]["model.0.conv.weight"]).all() and float(grads[0]["model.0.conv.weight"].abs().max()) > 0
-    for k in grads[0]:
-        assert torch.equal(grads[0][k], grads[1][k]), k
